@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REFERENCE itself.
+
+Run ONLY in the build container (needs /root/reference; it never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Recipe: import the real `transformers`/`datasets`, stub
+the absent third-party packages that are touched only OFF the hot path
+(torchvision, kornia, segmentation_models_pytorch), then import the
+reference's `models.*`.  Weights and inputs come from `oracle.fill`
+(pure functions of name/shape/seed), so fixtures hold expected OUTPUTS only.
+All arithmetic: PyTorch CPU fp32, torch.set_num_threads(1) for run-to-run
+stable reductions.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import transformers, datasets  # noqa: E401,F401  (real packages first)
+
+for _n in ["torchvision", "torchvision.models", "torchvision.transforms", "torchvision.transforms.v2",
+           "kornia", "kornia.augmentation", "kornia.filters", "segmentation_models_pytorch"]:
+    sys.modules[_n] = MagicMock()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from models.UNet import UNet, LargeUNet  # noqa: E402  (reference)
+from models.processing_blocks import (ConvBlock, ConvBlockDownsample, ConvBlockUpsampleSkip,  # noqa: E402
+                                      ConvBlockUpsample, CrossAttentionFusion)
+from models.losses import HybridLoss, IoU, IoUBinary, PixelAccuracy, PixelAccuracyBinary  # noqa: E402
+import models.CLIP_models as ref_clip  # noqa: E402
+
+from oracle import fill  # noqa: E402
+
+torch.set_num_threads(1)
+
+
+def T(name, shape, lo=0.0, hi=1.0):
+    return torch.from_numpy(fill.uniform(name, shape, lo, hi))
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+# ------------------------------------------------------------------ block-level fixtures
+BLOCK_CASES = [
+    # name, class, ctor args, input shapes (x[, skip])
+    ("cb_4_8", "ConvBlock", (4, 8), [(2, 4, 16, 16)]),
+    ("cb_32_64", "ConvBlock", (32, 64), [(2, 32, 16, 16)]),
+    ("cb_8_8_odd", "ConvBlock", (8, 8), [(1, 8, 8, 24)]),
+    ("down_8_16", "ConvBlockDownsample", (8, 16), [(2, 8, 16, 16)]),
+    ("upskip_16_8_identity", "ConvBlockUpsampleSkip", (16, 8), [(2, 16, 8, 8), (2, 8, 16, 16)]),
+    ("upskip_16_8_dec1", "ConvBlockUpsampleSkip", (16, 8), [(2, 16, 8, 8), (2, 8, 8, 8)]),
+    ("upskip_64_32_dec1", "ConvBlockUpsampleSkip", (64, 32), [(1, 64, 4, 12), (1, 32, 4, 12)]),
+    ("up_16_8", "ConvBlockUpsample", (16, 8), [(2, 16, 8, 8)]),
+]
+_CLS = dict(ConvBlock=ConvBlock, ConvBlockDownsample=ConvBlockDownsample,
+            ConvBlockUpsampleSkip=ConvBlockUpsampleSkip, ConvBlockUpsample=ConvBlockUpsample)
+
+
+def gen_blocks():
+    out = {}
+    for name, cls, args, shapes in BLOCK_CASES:
+        m = _CLS[cls](*args)
+        fill.fill_state_dict(m.state_dict(), prefix=name + ".")
+        ins = [T(f"{name}.in{i}", s, -1.0, 1.0).requires_grad_(True) for i, s in enumerate(shapes)]
+        # eval first (running stats as filled), then train
+        m.eval()
+        with torch.no_grad():
+            out[f"{name}/eval_out"] = npy(m(*ins))
+        m.train()
+        y = m(*ins)
+        g = T(f"{name}.gout", tuple(y.shape), -1.0, 1.0)
+        (y * g).sum().backward()
+        out[f"{name}/train_out"] = npy(y)
+        for i, t in enumerate(ins):
+            out[f"{name}/grad_in{i}"] = npy(t.grad)
+        for k, p in m.named_parameters():
+            out[f"{name}/grad/{k}"] = npy(p.grad)
+        for k, b in m.named_buffers():
+            out[f"{name}/buf/{k}"] = npy(b)
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+    print("blocks.npz", len(out))
+
+
+# ------------------------------------------------------------------ whole-model fixtures
+def _model_case(out, tag, model, x, target, adam_steps=0, grad_keys=()):
+    fill.fill_state_dict(model.state_dict())
+    model.eval()
+    with torch.no_grad():
+        out[f"{tag}/eval_logits"] = npy(model(x))
+    model.train()
+    logits = model(x)
+    loss = HybridLoss()(logits, target)
+    loss.backward()
+    out[f"{tag}/train_logits"] = npy(logits)
+    out[f"{tag}/ce_loss"] = npy(loss)
+    for k, p in model.named_parameters():
+        g = p.grad
+        out[f"{tag}/gradstat/{k}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()),
+                                               float(g.double().pow(2).sum())])
+        if k in grad_keys:
+            out[f"{tag}/grad/{k}"] = npy(g)
+    for k in ("enc1.block.0.conv.1.running_mean", "enc1.block.0.conv.1.running_var",
+              "bottleneck.conv.4.running_mean", "bottleneck.conv.4.running_var",
+              "bottleneck.conv.4.num_batches_tracked"):
+        out[f"{tag}/buf/{k}"] = npy(model.state_dict()[k])
+    if adam_steps:
+        # loop body of models/model_wrappers.py:167-177 (fp32, no autocast): Adam lr 1e-3 wd 1e-4
+        fill.fill_state_dict(model.state_dict())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        traj = []
+        for _ in range(adam_steps):
+            opt.zero_grad()
+            l = HybridLoss()(model(x), target)
+            l.backward()
+            opt.step()
+            traj.append(float(l))
+        out[f"{tag}/adam_traj"] = np.array(traj)
+
+
+def gen_models():
+    out = {}
+    x = T("c1.x", (2, 3, 128, 128))
+    t = torch.from_numpy(fill.randint("c1.t", (2, 128, 128), 3))
+    _model_case(out, "unet_c1", UNet(), x, t, adam_steps=5,
+                grad_keys=("input.weight", "input.bias", "enc1.block.0.conv.0.weight",
+                           "enc1.block.0.conv.1.weight", "enc1.block.0.conv.1.bias",
+                           "bottleneck.conv.3.bias", "dec1.up.bias", "dec4.up.weight",
+                           "dec4.conv.conv.3.weight", "out.weight", "out.bias"))
+    x = T("large.x", (1, 3, 64, 64))
+    t = torch.from_numpy(fill.randint("large.t", (1, 64, 64), 3))
+    _model_case(out, "large_64", LargeUNet(), x, t,
+                grad_keys=("input.weight", "out.weight", "dec5.up.bias"))
+    # odd-ish geometry (ClipUnet config 5 is 224 -> 28x28 at the bottleneck)
+    x = T("unet56.x", (1, 3, 56, 40))
+    t = torch.from_numpy(fill.randint("unet56.t", (1, 56, 40), 3))
+    _model_case(out, "unet_56x40", UNet(), x, t, grad_keys=("input.weight", "out.weight"))
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+    print("models.npz", len(out))
+
+
+def gen_clip():
+    """ClipUnet trunk with an injected feature extractor (the real one is a network fetch)."""
+    out = {}
+    feats = T("clip.feats", (2, 512), -1.0, 1.0)
+
+    class FakeExtractor(nn.Module):
+        def __init__(self, train=False):
+            super().__init__()
+
+        def forward(self, x):
+            return feats
+
+    ref_clip.ClipFeatureExtractor = FakeExtractor
+    m = ref_clip.ClipUnet()
+    fill.fill_state_dict(m.state_dict())
+    x = T("clip.x", (2, 3, 32, 32))
+    t = torch.from_numpy(fill.randint("clip.t", (2, 32, 32), 3))
+    m.eval()
+    with torch.no_grad():
+        out["clip/eval_logits"] = npy(m(x))
+    m.train()
+    logits = m(x)
+    loss = HybridLoss()(logits, t)
+    loss.backward()
+    out["clip/train_logits"] = npy(logits)
+    out["clip/ce_loss"] = npy(loss)
+    for k, p in m.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out[f"clip/gradstat/{k}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()),
+                                              float(g.double().pow(2).sum())])
+    out["clip/grad/out_proj.bias"] = npy(m.cross_attention_fusion.cross_attn.out_proj.bias.grad)
+    out["clip/grad/in_proj_weight_rowabs"] = npy(m.cross_attention_fusion.cross_attn.in_proj_weight.grad.abs().sum(1))
+    # the fusion module alone
+    caf = CrossAttentionFusion(512, num_heads=1)
+    fill.fill_state_dict(caf.state_dict(), prefix="cross_attention_fusion.")
+    b = T("caf.bott", (2, 512, 4, 4), -1.0, 1.0)
+    with torch.no_grad():
+        out["caf/out"] = npy(caf(b, feats))
+    np.savez_compressed(os.path.join(HERE, "clip.npz"), **out)
+    print("clip.npz", len(out))
+
+
+def gen_losses():
+    out = {}
+    logits = T("loss.logits", (2, 3, 32, 32), -3.0, 3.0)
+    tgt = torch.from_numpy(fill.randint("loss.t", (2, 32, 32), 3))
+    lg = logits.clone().requires_grad_(True)
+    ce = HybridLoss()(lg, tgt)
+    ce.backward()
+    out["ce"] = npy(ce)
+    out["ce_grad"] = npy(lg.grad)
+    out["iou"] = npy(IoU()(logits, tgt))
+    out["pixel_accuracy"] = npy(PixelAccuracy()(logits, tgt))
+    # missing-class case for PixelAccuracy (class 2 absent)
+    tgt2 = torch.from_numpy(fill.randint("loss.t2", (2, 32, 32), 2))
+    out["iou_2cls"] = npy(IoU()(logits, tgt2))
+    out["pixel_accuracy_2cls"] = npy(PixelAccuracy()(logits, tgt2))
+    bl = T("loss.blogits", (2, 1, 32, 32), -3.0, 3.0)
+    bt = torch.from_numpy(fill.randint("loss.bt", (2, 32, 32), 2)).float()
+    # BCE half of HybridLossBinary (models/losses.py:33); the Dice half is smp (absent) -> unpinned
+    blg = bl.clone().requires_grad_(True)
+    bce = nn.BCEWithLogitsLoss()(blg, bt.unsqueeze(1))
+    bce.backward()
+    out["bce"] = npy(bce)
+    out["bce_grad"] = npy(blg.grad)
+    out["iou_binary"] = npy(IoUBinary()(bl, bt))
+    out["pixel_accuracy_binary"] = npy(PixelAccuracyBinary()(bl, bt))
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses.npz", len(out))
+
+
+if __name__ == "__main__":
+    gen_blocks()
+    gen_models()
+    gen_clip()
+    gen_losses()
