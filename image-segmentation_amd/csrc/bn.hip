@@ -1,0 +1,569 @@
+// BatchNorm2d (+ReLU, +MaxPool2d(2,2)) forward/backward pieces and per-channel reductions, NHWC.
+// All kernels are HBM-bound: 16-byte vector accesses (8 bf16 / 4 f32 channels per lane), fp32
+// math, per-channel sums reduced lane -> LDS -> per-block partial -> fixed-order finalize.
+#include "common.h"
+
+namespace {
+
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+    if constexpr (V == 1) {
+        v[0] = (float)p[0];
+    } else {
+        const typename VecOf<T>::type t = *reinterpret_cast<const typename VecOf<T>::type*>(p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = (float)t[e];
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+    if constexpr (V == 1) {
+        p[0] = (T)v[0];
+    } else {
+        typename VecOf<T>::type t;
+#pragma unroll
+        for (int e = 0; e < V; ++e) t[e] = (T)v[e];
+        *reinterpret_cast<typename VecOf<T>::type*>(p) = t;
+    }
+}
+
+// ------------------------------------------------------------------ finalize of the conv-epilogue statistics
+// stats: [mtiles][2][C]; block = 16 channels x 16 tile slices, double accumulation.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* running_mean, float* running_var,
+                                                           long long* nbt, float* mean, float* invstd, float* scale,
+                                                           float* shift) {
+    __shared__ double sS[16][17], sQ[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double S = 0.0, Q = 0.0;
+    if (c < C) {
+        for (int t = sl; t < mtiles; t += 16) {
+            S += (double)stats[((size_t)t * 2 + 0) * C + c];
+            Q += (double)stats[((size_t)t * 2 + 1) * C + c];
+        }
+    }
+    sS[sl][cl] = S;
+    sQ[sl][cl] = Q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        S = 0.0;
+        Q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            S += sS[i][cl];
+            Q += sQ[i][cl];
+        }
+        const double m = S / count;
+        double var = Q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * is;
+        mean[c] = (float)m;
+        invstd[c] = is;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)m * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float is = 1.f / sqrtf(rv[c] + eps);
+        const float sc = gamma[c] * is;
+        mean[c] = rm[c];
+        invstd[c] = is;
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ------------------------------------------------------------------ y = [maxpool2x2](relu(x*scale + shift))
+template <typename T, int V, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y,
+                                                             int B, int H, int W, int C) {
+    const int CG = C / V;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const long total = (long)B * Ho * Wo * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const long op = i / CG;
+        float sc[V], sh[V], o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            sc[e] = scale[cg * V + e];
+            sh[e] = shift[cg * V + e];
+        }
+        if (!POOL) {
+            float v[V];
+            ldv<T, V>(x + op * C + cg * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+        } else {
+            const int xo = (int)(op % Wo);
+            const int yo = (int)((op / Wo) % Ho);
+            const long n = op / ((long)Wo * Ho);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = 0.f;  // relu output >= 0
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long ip = (n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+                float v[V];
+                ldv<T, V>(x + ip * C + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = fmaxf(o[e], v[e] * sc[e] + sh[e]);
+            }
+        }
+        stv<T, V>(y + op * C + cg * V, o);
+    }
+}
+
+// ------------------------------------------------------------------ block geometry of the channel reductions
+// thread -> (channel group cg = tid % CG, pixel lane pl = tid / CG); PL = 256 / CG pixel lanes.
+struct RedGeo {
+    int CG, PL, nblk;
+    long ppb;  // pixels per block
+};
+inline RedGeo red_geo(long npix, int C, int V) {
+    RedGeo g;
+    g.CG = C / V;
+    g.PL = 256 / g.CG;
+    long nb = (npix + (long)g.PL * 8 - 1) / ((long)g.PL * 8);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    g.nblk = (int)nb;
+    g.ppb = (npix + nb - 1) / nb;
+    return g;
+}
+inline int vec_for(int C, int dtype) {
+    const int v = dtype == HIPSEG_BF16 ? 8 : 4;
+    return (C % v == 0) ? v : 1;
+}
+
+// g routed through maxpool + relu for one output pixel; fills per-position y>0 / argmax decisions.
+// Shared by reduce and apply so both make identical decisions.
+template <typename T, int V, bool POOL>
+struct PixelCtx {
+    float xh[POOL ? 4 : 1][V];  // xhat
+    float g[POOL ? 4 : 1][V];   // routed gradient
+    long ip[POOL ? 4 : 1];
+    __device__ __forceinline__ void load(const T* x, const T* dy, const float (&mean)[V], const float (&invstd)[V],
+                                         const float (&sc)[V], const float (&sh)[V], long op, int cg, int H, int W,
+                                         int C) {
+        float gv[V];
+        ldv<T, V>(dy + op * C + cg * V, gv);
+        if (!POOL) {
+            ip[0] = op;
+            float v[V];
+            ldv<T, V>(x + op * C + cg * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                xh[0][e] = (v[e] - mean[e]) * invstd[e];
+                g[0][e] = (v[e] * sc[e] + sh[e] > 0.f) ? gv[e] : 0.f;
+            }
+        } else {
+            const int Ho = H / 2, Wo = W / 2;
+            const int xo = (int)(op % Wo);
+            const int yo = (int)((op / Wo) % Ho);
+            const long n = op / ((long)Wo * Ho);
+            float best[V];
+            int bk[V];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ip[k] = (n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+                float v[V];
+                ldv<T, V>(x + ip[k] * C + cg * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[k][e] = (v[e] - mean[e]) * invstd[e];
+                    const float yv = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                    if (k == 0 || yv > best[e]) {  // first maximum wins (window scan order)
+                        best[e] = yv;
+                        bk[e] = k;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[k][e] = (bk[e] == k && best[e] > 0.f) ? gv[e] : 0.f;
+        }
+    }
+};
+
+template <typename T, int V, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             float* __restrict__ partial, long npix_out, int H, int W,
+                                                             int C, int CG, int PL, long ppb) {
+    __shared__ float red[2 * 2048];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s1[e] = s2[e] = 0.f;
+    if (pl < PL) {
+        float mn[V], is[V], sc[V], sh[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            mn[e] = mean[cg * V + e];
+            is[e] = invstd[cg * V + e];
+            sc[e] = scale[cg * V + e];
+            sh[e] = shift[cg * V + e];
+        }
+        const long start = blockIdx.x * ppb;
+        long end = start + ppb;
+        if (end > npix_out) end = npix_out;
+        for (long op = start + pl; op < end; op += PL) {
+            PixelCtx<T, V, POOL> ctx;
+            ctx.load(x, dy, mn, is, sc, sh, op, cg, H, W, C);
+#pragma unroll
+            for (int k = 0; k < (POOL ? 4 : 1); ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    s1[e] += ctx.g[k][e];
+                    s2[e] += ctx.g[k][e] * ctx.xh[k][e];
+                }
+        }
+    }
+    // reduce over pixel lanes: red[pl][2][C] would be large; do a two-step tree in LDS over pl.
+    // layout red[r][pl_slot][c] with at most 2048 floats per r -> process in rounds of R = 2048/C lanes
+    const int R = 2048 / C;  // >= 1 because C <= 2048
+    float* r1 = red;
+    float* r2 = red + 2048;
+    float t1[V], t2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) t1[e] = t2[e] = 0.f;
+    for (int base = 0; base < PL; base += R) {
+        __syncthreads();
+        if (pl >= base && pl < base + R && pl < PL) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                r1[(pl - base) * C + cg * V + e] = s1[e];
+                r2[(pl - base) * C + cg * V + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (pl == 0) {
+            const int lim = (PL - base) < R ? (PL - base) : R;
+            for (int j = 0; j < lim; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    t1[e] += r1[j * C + cg * V + e];
+                    t2[e] += r2[j * C + cg * V + e];
+                }
+        }
+    }
+    if (pl == 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            partial[((size_t)blockIdx.x * 2 + 0) * C + cg * V + e] = t1[e];
+            partial[((size_t)blockIdx.x * 2 + 1) * C + cg * V + e] = t2[e];
+        }
+    }
+}
+
+template <typename T, int V, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ sums, float inv_count, int eval,
+                                                            T* __restrict__ dx, float* dbias, long npix_out, int H,
+                                                            int W, int C, int CG, int PL, long ppb) {
+    __shared__ float red[2048];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    float sb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sb[e] = 0.f;
+    if (pl < PL) {
+        float mn[V], is[V], sc[V], sh[V], k1[V], k2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            mn[e] = mean[cg * V + e];
+            is[e] = invstd[cg * V + e];
+            sc[e] = scale[cg * V + e];
+            sh[e] = shift[cg * V + e];
+            k1[e] = eval ? 0.f : sums[cg * V + e] * inv_count;      // dbeta / N
+            k2[e] = eval ? 0.f : sums[C + cg * V + e] * inv_count;  // dgamma / N
+        }
+        const long start = blockIdx.x * ppb;
+        long end = start + ppb;
+        if (end > npix_out) end = npix_out;
+        for (long op = start + pl; op < end; op += PL) {
+            PixelCtx<T, V, POOL> ctx;
+            ctx.load(x, dy, mn, is, sc, sh, op, cg, H, W, C);
+#pragma unroll
+            for (int k = 0; k < (POOL ? 4 : 1); ++k) {
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    o[e] = sc[e] * (ctx.g[k][e] - k1[e] - ctx.xh[k][e] * k2[e]);
+                    sb[e] += o[e];
+                }
+                stv<T, V>(dx + ctx.ip[k] * C + cg * V, o);
+            }
+        }
+    }
+    if (dbias) {  // conv-bias gradient = per-channel sum of dx (uniform branch)
+        const int R = 2048 / C;
+        float t[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) t[e] = 0.f;
+        for (int base = 0; base < PL; base += R) {
+            __syncthreads();
+            if (pl >= base && pl < base + R && pl < PL) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) red[(pl - base) * C + cg * V + e] = sb[e];
+            }
+            __syncthreads();
+            if (pl == 0) {
+                const int lim = (PL - base) < R ? (PL - base) : R;
+                for (int j = 0; j < lim; ++j)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) t[e] += red[j * C + cg * V + e];
+            }
+        }
+        if (pl == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) atomicAdd(dbias + cg * V + e, t[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ per-channel sum over pixels
+template <typename T, int V>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, long npix,
+                                                      int C, int CG, int PL, long ppb) {
+    __shared__ float red[2048];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (pl < PL) {
+        const long start = blockIdx.x * ppb;
+        long end = start + ppb;
+        if (end > npix) end = npix;
+        for (long p = start + pl; p < end; p += PL) {
+            float v[V];
+            ldv<T, V>(x + p * C + cg * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += v[e];
+        }
+    }
+    const int R = 2048 / C;
+    float t[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) t[e] = 0.f;
+    for (int base = 0; base < PL; base += R) {
+        __syncthreads();
+        if (pl >= base && pl < base + R && pl < PL) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[(pl - base) * C + cg * V + e] = s[e];
+        }
+        __syncthreads();
+        if (pl == 0) {
+            const int lim = (PL - base) < R ? (PL - base) : R;
+            for (int j = 0; j < lim; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) t[e] += red[j * C + cg * V + e];
+        }
+    }
+    if (pl == 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) partial[(size_t)blockIdx.x * C + cg * V + e] = t[e];
+    }
+}
+
+// out[r][c] = sum_blk partial[blk][r][c]; block = 64 columns x 4 block-slices, fixed order.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int RC,
+                                                               float* __restrict__ out) {
+    __shared__ float sm[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < RC)
+        for (int b = sl; b < nblk; b += 4) s += partial[(size_t)b * RC + c];
+    sm[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < RC) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
+#define DISPATCH_TV(dtype, V, ...)                              \
+    do {                                                        \
+        if (dtype == HIPSEG_BF16) {                             \
+            typedef bf16 T_;                                    \
+            if (V == 8) {                                       \
+                constexpr int V_ = 8;                           \
+                __VA_ARGS__                                     \
+            } else {                                            \
+                constexpr int V_ = 1;                           \
+                __VA_ARGS__                                     \
+            }                                                   \
+        } else {                                                \
+            typedef float T_;                                   \
+            if (V == 4) {                                       \
+                constexpr int V_ = 4;                           \
+                __VA_ARGS__                                     \
+            } else {                                            \
+                constexpr int V_ = 1;                           \
+                __VA_ARGS__                                     \
+            }                                                   \
+        }                                                       \
+    } while (0)
+
+}  // namespace
+
+extern "C" int hipseg_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean,
+                                  float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                                  float* scale, float* shift, hipseg_stream_t stream) {
+    HS_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && C > 0 && mtiles > 0 && count > 0,
+               "bn_finalize: bad arguments");
+    HS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var mismatch");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                       reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale, shift);
+    HS_LAUNCH_CHECK("bn_finalize");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float eps, int C, float* mean, float* invstd,
+                                     float* scale, float* shift, hipseg_stream_t stream) {
+    HS_REQUIRE(gamma && beta && running_mean && running_var && mean && invstd && scale && shift && C > 0,
+               "bn_eval_params: bad arguments");
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gamma, beta, running_mean, running_var, eps, C, mean,
+                       invstd, scale, shift);
+    HS_LAUNCH_CHECK("bn_eval_params");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, int B,
+                                    int H, int W, int C, int pool, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_relu_apply: bad dtype");
+    HS_REQUIRE(x && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0, "bn_relu_apply: bad arguments");
+    HS_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "bn_relu_apply: pooling needs even H, W (got %d,%d)", H, W);
+    const int V = vec_for(C, dtype);
+    const long total = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / V);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        if (pool)
+            hipLaunchKernelGGL((bn_relu_apply_kernel<T_, V_, true>), dim3((unsigned)g), dim3(256), 0, s, (const T_*)x,
+                               scale, shift, (T_*)y, B, H, W, C);
+        else
+            hipLaunchKernelGGL((bn_relu_apply_kernel<T_, V_, false>), dim3((unsigned)g), dim3(256), 0, s,
+                               (const T_*)x, scale, shift, (T_*)y, B, H, W, C);
+    });
+    HS_LAUNCH_CHECK("bn_relu_apply");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bn_bwd_blocks(int B, int H, int W, int C, int dtype, int pool) {
+    const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    return red_geo(npix, C, vec_for(C, dtype)).nblk;
+}
+
+static int check_red(const char* name, int C, int V) {
+    HS_REQUIRE(C / V <= 256 && C <= 2048, "%s: unsupported channel count %d (vector width %d)", name, C, V);
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, float* partial, int B, int H, int W,
+                                    int C, int pool, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_bwd_reduce: bad dtype");
+    HS_REQUIRE(dy && x && mean && invstd && scale && shift && partial && B > 0 && H > 0 && W > 0 && C > 0,
+               "bn_bwd_reduce: bad arguments");
+    HS_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "bn_bwd_reduce: pooling needs even H, W");
+    const int V = vec_for(C, dtype);
+    if (int rc = check_red("bn_bwd_reduce", C, V)) return rc;
+    const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const RedGeo g = red_geo(npix, C, V);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        if (pool)
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, V_, true>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
+                               (const T_*)x, mean, invstd, scale, shift, partial, npix, H, W, C, g.CG, g.PL, g.ppb);
+        else
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, V_, false>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
+                               (const T_*)x, mean, invstd, scale, shift, partial, npix, H, W, C, g.CG, g.PL, g.ppb);
+    });
+    HS_LAUNCH_CHECK("bn_bwd_reduce");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, const float* sums, double count, int eval,
+                                   void* dx, float* dbias, int B, int H, int W, int C, int pool,
+                                   hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_bwd_apply: bad dtype");
+    HS_REQUIRE(dy && x && mean && invstd && scale && shift && dx && (eval || sums) && count > 0 && C > 0,
+               "bn_bwd_apply: bad arguments");
+    HS_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "bn_bwd_apply: pooling needs even H, W");
+    const int V = vec_for(C, dtype);
+    if (int rc = check_red("bn_bwd_apply", C, V)) return rc;
+    const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    const RedGeo g = red_geo(npix, C, V);
+    const float inv = (float)(1.0 / count);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        if (pool)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, V_, true>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
+                               (const T_*)x, mean, invstd, scale, shift, sums, inv, eval, (T_*)dx, dbias, npix, H, W,
+                               C, g.CG, g.PL, g.ppb);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, V_, false>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
+                               (const T_*)x, mean, invstd, scale, shift, sums, inv, eval, (T_*)dx, dbias, npix, H, W,
+                               C, g.CG, g.PL, g.ppb);
+    });
+    HS_LAUNCH_CHECK("bn_bwd_apply");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_colsum_finalize(const float* partial, int nblk, int rows, int C, float* out,
+                                      hipseg_stream_t stream) {
+    HS_REQUIRE(partial && out && nblk > 0 && rows > 0 && C > 0, "colsum_finalize: bad arguments");
+    const int RC = rows * C;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 64)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), partial, nblk, RC, out);
+    HS_LAUNCH_CHECK("colsum_finalize");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_colsum_blocks(long npix, int C, int dtype) { return red_geo(npix, C, vec_for(C, dtype)).nblk; }
+
+extern "C" int hipseg_colsum(int dtype, const void* x, long npix, int C, float* partial, float* out,
+                             hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "colsum: bad dtype");
+    HS_REQUIRE(x && partial && out && npix > 0 && C > 0, "colsum: bad arguments");
+    const int V = vec_for(C, dtype);
+    if (int rc = check_red("colsum", C, V)) return rc;
+    const RedGeo g = red_geo(npix, C, V);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((colsum_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, (const T_*)x, partial, npix, C,
+                           g.CG, g.PL, g.ppb);
+    });
+    HS_LAUNCH_CHECK("colsum");
+    return hipseg_colsum_finalize(partial, g.nblk, 1, C, out, stream);
+}

@@ -1,0 +1,81 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/hipseg.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- error plumbing (host)
+void hipseg_set_error(const char* fmt, ...);
+
+#define HS_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            hipseg_set_error(__VA_ARGS__); \
+            return HIPSEG_EINVAL;      \
+        }                              \
+    } while (0)
+
+#define HS_LAUNCH_CHECK(name)                                                    \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            hipseg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return HIPSEG_EHIP;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- per-dtype traits
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+    static constexpr int N = 4;  // elements per 16-byte vector
+    typedef f32x4 type;
+};
+template <>
+struct VecOf<bf16> {
+    static constexpr int N = 8;
+    typedef bf16x8 type;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// 16-byte vector load/store of VecOf<T>::N elements into/from a float array
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float (&v)[VecOf<T>::N]) {
+    typename VecOf<T>::type t = *reinterpret_cast<const typename VecOf<T>::type*>(p);
+#pragma unroll
+    for (int i = 0; i < VecOf<T>::N; ++i) v[i] = (float)t[i];
+}
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[VecOf<T>::N]) {
+    typename VecOf<T>::type t;
+#pragma unroll
+    for (int i = 0; i < VecOf<T>::N; ++i) t[i] = (T)v[i];
+    *reinterpret_cast<typename VecOf<T>::type*>(p) = t;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

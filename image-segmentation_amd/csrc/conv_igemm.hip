@@ -1,0 +1,394 @@
+// Implicit-GEMM convolution for gfx950 (MFMA), NHWC activations.
+//
+//   M = output pixels, tiled 16x16 per workgroup (BM = 256)
+//   N = output channels, tile BN in {32, 64, 128}
+//   K = taps x input channels, consumed in chunks of KC channels x ALL taps
+//
+// Per K-chunk the workgroup stages (a) the input HALO tile (18x18 pixels for a 3x3 conv)
+// once into LDS and re-uses it for all 9 taps, and (b) the packed weights of the chunk.
+// LDS images are "k-group major" ([k/G][pixel or column][G], G = 8 bf16 / 1 f32) so that an MFMA
+// operand fragment is one conflict-free ds_read_b128 (bf16) / ds_read_b32 (f32) per lane.
+//
+//   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate
+//   f32 : v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) -- the 1e-4 parity mode
+//
+// The epilogue adds the bias, stores NHWC (optionally split over two destination tensors, or
+// pixel-shuffled for ConvTranspose2d) and reduces the per-tile BatchNorm partial sums.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, BM = TH * TW;
+
+template <typename T>
+struct KT;
+template <>
+struct KT<bf16> {
+    static constexpr int G = 8, KC = 16;
+};
+template <>
+struct KT<float> {
+    static constexpr int G = 1, KC = 8;
+};
+
+template <int MODE>
+struct Geo;
+template <>
+struct Geo<HIPSEG_CONV3> {
+    static constexpr int HH = TH + 2, HW = TW + 2, NT = 9;
+};
+template <>
+struct Geo<HIPSEG_CONV1> {
+    static constexpr int HH = TH, HW = TW, NT = 1;
+};
+template <>
+struct Geo<HIPSEG_CONV2S2> {
+    static constexpr int HH = 2 * TH, HW = 2 * TW, NT = 4;
+};
+template <>
+struct Geo<HIPSEG_CONVT> {
+    static constexpr int HH = TH, HW = TW, NT = 1;
+};
+
+struct ConvArgs {
+    const void* in0;
+    const void* in1;
+    const void* wp;
+    const float* bias;
+    void* out0;
+    void* out1;
+    float* stats;
+    int C0, C1, N0, N1;
+    int B, H, W;    // GEMM-M pixel grid
+    int Hi, Wi;     // input spatial dims
+    int K, Kp, N, Np;
+    int tiles_x, tiles_y, ntn;
+    int vec_ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ constexpr int tap_off(int tap) {
+    if (MODE == HIPSEG_CONV3) return (tap / 3) * Geo<MODE>::HW + (tap % 3);
+    if (MODE == HIPSEG_CONV2S2) return (tap >> 1) * Geo<MODE>::HW + (tap & 1);
+    return 0;
+}
+
+template <typename T, int MODE, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int G = KT<T>::G, KC = KT<T>::KC, KG = KC / G;
+    constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int VEC = VecOf<T>::N;
+    constexpr int CV = KC / VEC;
+    typedef typename VecOf<T>::type vec_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* sA = reinterpret_cast<T*>(smem);  // [KG][NPIX][G]
+    T* sB = sA + KC * NPIX;              // [NT][KG][BN][G]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntile = blockIdx.x % p.ntn;
+    const int mtile = blockIdx.x / p.ntn;
+    const int tx = mtile % p.tiles_x;
+    const int ty = (mtile / p.tiles_x) % p.tiles_y;
+    const int img = mtile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = ntile * BN;
+
+    // halo origin in input coordinates
+    int oy, ox;
+    if (MODE == HIPSEG_CONV3) {
+        oy = y0 - 1;
+        ox = x0 - 1;
+    } else if (MODE == HIPSEG_CONV2S2) {
+        oy = 2 * y0;
+        ox = 2 * x0;
+    } else {
+        oy = y0;
+        ox = x0;
+    }
+
+    const T* in0 = reinterpret_cast<const T*>(p.in0);
+    const T* in1 = reinterpret_cast<const T*>(p.in1);
+    const T* wp = reinterpret_cast<const T*>(p.wp);
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // per-lane halo base index of each M sub-tile (32 pixels = 2 tile rows x 16)
+    int hbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = r & 15;
+        if (MODE == HIPSEG_CONV2S2)
+            hbase[i] = (2 * py) * HW + 2 * px;
+        else
+            hbase[i] = py * HW + px;
+    }
+    int ncol[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
+
+    const int kgp = p.Kp / G;
+
+    for (int c0 = 0; c0 < p.Kp; c0 += KC) {
+        __syncthreads();  // previous chunk's fragment reads are done
+        // ---------------- stage A: halo tile, KC channels
+        constexpr int NCELL = NPIX * CV;
+#pragma unroll
+        for (int it = 0; it < (NCELL + 255) / 256; ++it) {
+            const int cell = it * 256 + tid;
+            if (cell < NCELL) {
+                const int pix = cell / CV, cv = cell % CV;
+                const int hy = pix / HW, hx = pix % HW;
+                const int iy = oy + hy, ix = ox + hx;
+                const int c = c0 + cv * VEC;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.K) {
+                    const long pixoff = ((long)img * p.Hi + iy) * p.Wi + ix;
+                    if (p.vec_ok) {
+                        const T* src = (c < p.C0) ? in0 + pixoff * p.C0 + c : in1 + pixoff * p.C1 + (c - p.C0);
+                        v = *reinterpret_cast<const vec_t*>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int cc = c + e;
+                            if (cc < p.K)
+                                v[e] = (cc < p.C0) ? in0[pixoff * p.C0 + cc] : in1[pixoff * p.C1 + (cc - p.C0)];
+                        }
+                    }
+                }
+                if (G == VEC) {
+                    *reinterpret_cast<vec_t*>(sA + ((size_t)cv * NPIX + pix) * G) = v;
+                } else {  // G == 1: channel-major scatter
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sA[(cv * VEC + e) * NPIX + pix] = v[e];
+                }
+            }
+        }
+        // ---------------- stage B: packed weights of this chunk, all taps (16-byte copies)
+        {
+            constexpr int RV = BN * G * (int)sizeof(T) / 16;  // 16B vectors per (tap, kg) run
+            constexpr int NV = NT * KG * RV;
+            const int kg0 = c0 / G;
+#pragma unroll
+            for (int it = 0; it < (NV + 255) / 256; ++it) {
+                const int v = it * 256 + tid;
+                if (v < NV) {
+                    const int run = v / RV, off = v % RV;
+                    const int tap = run / KG, kgl = run % KG;
+                    const T* src = wp + (((size_t)tap * kgp + kg0 + kgl) * p.Np + n0) * G;
+                    const uint4 val = reinterpret_cast<const uint4*>(src)[off];
+                    reinterpret_cast<uint4*>(sB + (size_t)run * BN * G)[off] = val;
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- MFMA over all taps of the chunk
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int toff = tap_off<MODE>(tap);
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 bf[NTL];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(tap * KG + h) * BN + ncol[j]) * 8);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bf16x8 af =
+                        *reinterpret_cast<const bf16x8*>(sA + ((size_t)h * NPIX + hbase[i] + toff) * 8);
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    const int k = 2 * kk + h;
+                    float bfv[NTL];
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) bfv[j] = sB[(size_t)(tap * KC + k) * BN + ncol[j]];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const float af = sA[(size_t)k * NPIX + hbase[i] + toff];
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfv[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: bias, store, BN partial statistics
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    float ssum[NTL], ssq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        ssum[j] = 0.f;
+        ssq[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int n = n0 + ncol[j];
+        const bool nok = n < p.N;
+        float bv = 0.f;
+        int co = n, ab = 0;
+        if (MODE == HIPSEG_CONVT) {
+            ab = n / p.N0;
+            co = n - ab * p.N0;
+        }
+        if (nok && p.bias) bv = p.bias[co];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // row inside the 32-pixel sub-tile
+                const int y = y0 + 2 * (wm * MT + i) + (rr >> 4), x = x0 + (rr & 15);
+                if (nok && y < p.H && x < p.W) {
+                    const float v = acc[i][j][e] + bv;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                    if (MODE == HIPSEG_CONVT) {
+                        const long opix = ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+                        out0[opix * p.N0 + co] = (T)v;
+                    } else {
+                        const long opix = ((long)img * p.H + y) * p.W + x;
+                        if (n < p.N0)
+                            out0[opix * p.N0 + n] = (T)v;
+                        else
+                            out1[opix * p.N1 + (n - p.N0)] = (T)v;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            ssum[j] += __shfl_xor(ssum[j], 32, 64);
+            ssq[j] += __shfl_xor(ssq[j], 32, 64);
+        }
+        __syncthreads();  // LDS is re-used as the cross-wave scratch
+        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
+                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                S += red[(w * 2 + 0) * BN + tid];
+                Q += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
+            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
+        }
+    }
+}
+
+template <typename T, int MODE, int BN>
+int launch(const ConvArgs& a, hipStream_t s) {
+    constexpr int KC = KT<T>::KC;
+    constexpr int NPIX = Geo<MODE>::HH * Geo<MODE>::HW, NT = Geo<MODE>::NT;
+    size_t lds = (size_t)(KC * NPIX + NT * KC * BN) * sizeof(T);
+    const size_t red = (size_t)4 * 2 * BN * sizeof(float);
+    if (lds < red) lds = red;
+    const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BN>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    HS_LAUNCH_CHECK("conv_igemm");
+    return HIPSEG_OK;
+}
+
+template <typename T, int MODE>
+int launch_bn(const ConvArgs& a, int bn, hipStream_t s) {
+    if (bn == 128) return launch<T, MODE, 128>(a, s);
+    if (bn == 64) return launch<T, MODE, 64>(a, s);
+    return launch<T, MODE, 32>(a, s);
+}
+
+template <typename T>
+int launch_mode(const ConvArgs& a, int mode, int bn, hipStream_t s) {
+    switch (mode) {
+        case HIPSEG_CONV3: return launch_bn<T, HIPSEG_CONV3>(a, bn, s);
+        case HIPSEG_CONV1: return launch_bn<T, HIPSEG_CONV1>(a, bn, s);
+        case HIPSEG_CONV2S2: return launch_bn<T, HIPSEG_CONV2S2>(a, bn, s);
+        default: return launch_bn<T, HIPSEG_CONVT>(a, bn, s);
+    }
+}
+
+int bn_for(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
+
+}  // namespace
+
+extern "C" int hipseg_kpad(int K, int dtype) {
+    const int kc = dtype == HIPSEG_BF16 ? KT<bf16>::KC : KT<float>::KC;
+    return (K + kc - 1) / kc * kc;
+}
+extern "C" int hipseg_npad(int N) {
+    const int bn = bn_for(N);
+    return (N + bn - 1) / bn * bn;
+}
+extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return B * cdiv(H, TH) * cdiv(W, TW); }
+
+extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
+                                 const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
+                                 float* stats, int B, int H, int W, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_igemm: bad dtype %d", dtype);
+    HS_REQUIRE(mode >= HIPSEG_CONV3 && mode <= HIPSEG_CONVT, "conv_igemm: bad mode %d", mode);
+    HS_REQUIRE(in0 && wp && out0 && C0 > 0 && N0 > 0, "conv_igemm: null operand or empty channel range");
+    HS_REQUIRE(B > 0 && H > 0 && W > 0, "conv_igemm: empty pixel grid (%d,%d,%d)", B, H, W);
+    HS_REQUIRE((C1 == 0) == (in1 == nullptr), "conv_igemm: in1/C1 mismatch");
+    HS_REQUIRE((N1 == 0) == (out1 == nullptr), "conv_igemm: out1/N1 mismatch");
+    HS_REQUIRE(!(mode == HIPSEG_CONVT && (N1 != 0 || stats)), "conv_igemm: CONVT takes one output, no stats");
+    ConvArgs a;
+    a.in0 = in0;
+    a.in1 = in1;
+    a.wp = wp;
+    a.bias = bias;
+    a.out0 = out0;
+    a.out1 = out1;
+    a.stats = stats;
+    a.C0 = C0;
+    a.C1 = C1;
+    a.N0 = N0;
+    a.N1 = N1;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.Hi = mode == HIPSEG_CONV2S2 ? 2 * H : H;
+    a.Wi = mode == HIPSEG_CONV2S2 ? 2 * W : W;
+    a.K = C0 + C1;
+    a.Kp = hipseg_kpad(a.K, dtype);
+    a.N = mode == HIPSEG_CONVT ? 4 * N0 : N0 + N1;
+    a.Np = hipseg_npad(a.N);
+    a.tiles_x = cdiv(W, TW);
+    a.tiles_y = cdiv(H, TH);
+    const int bn = bn_for(a.N);
+    a.ntn = a.Np / bn;
+    const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
+    a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16) return launch_mode<bf16>(a, mode, bn, s);
+    return launch_mode<float>(a, mode, bn, s);
+}

@@ -1,0 +1,342 @@
+// Weight-gradient GEMM for gfx950 (MFMA):  G[tap][u][v] = sum_pixels P[tap(pixel)][u] * Q[pixel][v]
+//
+// The reduction dimension is the pixel index, which is the OUTER dimension of NHWC tensors, so
+// both MFMA operands are needed "k-major".  The LDS images keep the global [pixel][channel] layout
+// (coalesced staging, any 3x3 tap is just a row offset into the halo image) and
+//   bf16: fragments come from ds_read_b64_tr_b16 (hardware transposed read, 4 pixels x 16 channels
+//         per 16-lane group), feeding v_mfma_f32_32x32x16_bf16;
+//   f32 : v_mfma_f32_32x32x2_f32 takes one float per lane, read straight from the image.
+// A workgroup owns one (u-tile, v-tile) pair for ALL taps (9 accumulator tiles per wave for a 3x3
+// conv) and walks a strided subset of the 16x16 pixel tiles; partial results go to fp32 slabs that a
+// second kernel sums in fixed order into the parameter's native layout (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16;
+
+template <typename T>
+struct WT;
+template <>
+struct WT<bf16> {
+    static constexpr int TH = 16, UC = 64, VC = 64, WU = 2, WV = 2, SWZ = 1;
+};
+template <>
+struct WT<float> {
+    static constexpr int TH = 8, UC = 32, VC = 128, WU = 1, WV = 4, SWZ = 0;
+};
+
+// bf16 images: 64-channel (128 B) rows; the 64-byte half a transposed read touches is XOR-swapped on
+// every second pixel pair so that the 4 pixel rows of one ds_read_b64_tr_b16 hit 4 different
+// 64-byte bank quarters (conflict-free without padding).
+template <typename T>
+__device__ __forceinline__ int swz(int pix) {
+    return WT<T>::SWZ ? ((pix >> 1) & 1) << 5 : 0;
+}
+
+struct WgArgs {
+    const void* p0;
+    const void* p1;
+    const void* q;
+    float* slabs;
+    int CU0, CU1, CU, CV, CUp, CVp;
+    int B, H, W;     // Q pixel grid
+    int PH, PW;      // P spatial dims
+    int ps, pa, pb;  // P pixel = (ps*y + pa, ps*x + pb)   (NT == 1 modes)
+    int tiles_x, tiles_y, ntiles, S, UT, VT;
+    int vec_ok_p, vec_ok_q;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
+    constexpr int TH = WT<T>::TH, UC = WT<T>::UC, VC = WT<T>::VC, WU = WT<T>::WU, WV = WT<T>::WV;
+    constexpr int PP = UC, QP = VC;  // LDS row pitch (elements)
+    constexpr int HALO = NT == 9 ? 1 : 0;
+    constexpr int PHH = TH + 2 * HALO, PHW = TW + 2 * HALO, NPP = PHH * PHW, NPQ = TH * TW;
+    constexpr int VEC = VecOf<T>::N;
+    typedef typename VecOf<T>::type vec_t;
+    static_assert(WU * WV == 4 && UC == 32 * WU && VC == 32 * WV, "one 32x32 block per wave");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* sP = reinterpret_cast<T*>(smem);  // [NPP][PP]
+    T* sQ = sP + NPP * PP;               // [NPQ][QP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wu = wave / WV, wv = wave % WV;
+
+    const int vt = blockIdx.x % a.VT;
+    const int ut = (blockIdx.x / a.VT) % a.UT;
+    const int s = blockIdx.x / (a.VT * a.UT);
+    const int u0 = ut * UC, v0 = vt * VC;
+
+    const T* p0 = reinterpret_cast<const T*>(a.p0);
+    const T* p1 = reinterpret_cast<const T*>(a.p1);
+    const T* q = reinterpret_cast<const T*>(a.q);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    for (int tile = s; tile < a.ntiles; tile += a.S) {
+        const int tx = tile % a.tiles_x;
+        const int ty = (tile / a.tiles_x) % a.tiles_y;
+        const int img = tile / (a.tiles_x * a.tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();
+        // ---------------- stage P (halo image for the 3x3 case), UC channels
+        {
+            constexpr int CVP = UC / VEC, NCELL = NPP * CVP;
+#pragma unroll 4
+            for (int cell = tid; cell < NCELL; cell += 256) {
+                const int pix = cell / CVP, cv = cell % CVP;
+                const int hy = pix / PHW, hx = pix % PHW;
+                const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;  // Q-grid coordinates
+                const int iy = a.ps * gy + a.pa, ix = a.ps * gx + a.pb;
+                const int c = u0 + cv * VEC;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.CU) {
+                    const long pixoff = ((long)img * a.PH + iy) * a.PW + ix;
+                    if (a.vec_ok_p) {
+                        const T* src = (c < a.CU0) ? p0 + pixoff * a.CU0 + c : p1 + pixoff * a.CU1 + (c - a.CU0);
+                        v = *reinterpret_cast<const vec_t*>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int cc = c + e;
+                            if (cc < a.CU)
+                                v[e] = (cc < a.CU0) ? p0[pixoff * a.CU0 + cc] : p1[pixoff * a.CU1 + (cc - a.CU0)];
+                        }
+                    }
+                }
+                *reinterpret_cast<vec_t*>(sP + (size_t)pix * PP + ((cv * VEC) ^ swz<T>(pix))) = v;
+            }
+        }
+        // ---------------- stage Q, VC channels
+        {
+            constexpr int CVQ = VC / VEC, NCELL = NPQ * CVQ;
+#pragma unroll 4
+            for (int cell = tid; cell < NCELL; cell += 256) {
+                const int pix = cell / CVQ, cv = cell % CVQ;
+                const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+                const int c = v0 + cv * VEC;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+                if (gy < a.H && gx < a.W && c < a.CV) {
+                    const long pixoff = ((long)img * a.H + gy) * a.W + gx;
+                    if (a.vec_ok_q) {
+                        v = *reinterpret_cast<const vec_t*>(q + pixoff * a.CV + c);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (c + e < a.CV) v[e] = q[pixoff * a.CV + c + e];
+                    }
+                }
+                *reinterpret_cast<vec_t*>(sQ + (size_t)pix * QP + ((cv * VEC) ^ swz<T>(pix))) = v;
+            }
+        }
+        __syncthreads();
+        // ---------------- MFMA: k runs over the pixels of the tile
+        if constexpr (sizeof(T) == 2) {
+            // transposed-read lane geometry: 16-lane group g = lane>>4 covers channels 16*(g&1)..+15,
+            // k half h = g>>1; lane 4q+p of the group addresses block row q, columns 4p..4p+3.
+            const int tq = (lane & 15) >> 2, tp = lane & 3;
+            const int chA = wu * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
+            const int chB = wv * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll 2
+            for (int y = 0; y < TH; ++y) {
+                const int kx0 = 8 * h + tq;  // pixel column (k) of this lane's first block row
+                bf16x8 bfrag;
+                {
+                    const bf16* bq = reinterpret_cast<const bf16*>(sQ);
+                    const int q0 = y * TW + kx0, q1 = q0 + 4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(bq + (size_t)q0 * QP + (chB ^ swz<T>(q0))));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(bq + (size_t)q1 * QP + (chB ^ swz<T>(q1))));
+                    bfrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int ky = NT == 9 ? t / 3 : 0, kx = NT == 9 ? t % 3 : 0;
+                    const bf16* ap = reinterpret_cast<const bf16*>(sP);
+                    const int a0 = (y + ky) * PHW + kx0 + kx, a1 = a0 + 4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(ap + (size_t)a0 * PP + (chA ^ swz<T>(a0))));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(ap + (size_t)a1 * PP + (chA ^ swz<T>(a1))));
+                    const bf16x8 afrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            const float* fP = reinterpret_cast<const float*>(sP);
+            const float* fQ = reinterpret_cast<const float*>(sQ);
+#pragma unroll 1
+            for (int y = 0; y < TH; ++y) {
+#pragma unroll
+                for (int kk = 0; kk < TW / 2; ++kk) {
+                    const int x = 2 * kk + h;
+                    const float bv = fQ[(size_t)(y * TW + x) * QP + wv * 32 + r];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int ky = NT == 9 ? t / 3 : 0, kx = NT == 9 ? t % 3 : 0;
+                        const float av = fP[(size_t)((y + ky) * PHW + x + kx) * PP + wu * 32 + r];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---------------- write this split's slab: [S][NT][CUp][CVp]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + r;
+            a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
+        }
+    }
+}
+
+// sum the S slabs in fixed order and scatter into the parameter's native layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, int NT,
+                                    int CU, int CV, int CUp, int CVp, int mode, int ab) {
+    const long total = (long)NT * CU * CV;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % CV);
+        const int u = (int)((i / CV) % CU);
+        const int t = (int)(i / ((long)CV * CU));
+        const size_t off = ((size_t)t * CUp + u) * CVp + v;
+        const size_t stride = (size_t)NT * CUp * CVp;
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += slabs[off + s * stride];
+        size_t o;
+        if (mode == HIPSEG_CONV3)
+            o = ((size_t)v * CU + u) * 9 + t;  // (Cout=v, Cin=u, ky, kx)
+        else if (mode == HIPSEG_CONV1)
+            o = (size_t)v * CU + u;  // (Cout=v, Cin=u)
+        else
+            o = ((size_t)v * CU + u) * 4 + ab;  // ConvT (Cin=v, Cout=u, a, b)
+        dw[o] = sum;
+    }
+}
+
+struct Plan {
+    int UT, VT, S, ntiles, tiles_x, tiles_y, CUp, CVp, NT;
+};
+
+template <typename T>
+Plan make_plan(int mode, int CU, int CV, int B, int H, int W) {
+    Plan p;
+    p.NT = mode == HIPSEG_CONV3 ? 9 : 1;
+    p.UT = cdiv(CU, WT<T>::UC);
+    p.VT = cdiv(CV, WT<T>::VC);
+    p.CUp = p.UT * WT<T>::UC;
+    p.CVp = p.VT * WT<T>::VC;
+    p.tiles_x = cdiv(W, TW);
+    p.tiles_y = cdiv(H, WT<T>::TH);
+    p.ntiles = B * p.tiles_x * p.tiles_y;
+    int S = 1024 / (p.UT * p.VT);
+    if (S < 1) S = 1;
+    if (S > p.ntiles) S = p.ntiles;
+    p.S = S;
+    return p;
+}
+
+Plan plan_for(int dtype, int mode, int CU, int CV, int B, int H, int W) {
+    return dtype == HIPSEG_BF16 ? make_plan<bf16>(mode, CU, CV, B, H, W) : make_plan<float>(mode, CU, CV, B, H, W);
+}
+
+template <typename T, int NT>
+int launch(const WgArgs& a, hipStream_t s) {
+    constexpr int HALO = NT == 9 ? 1 : 0;
+    constexpr int NPP = (WT<T>::TH + 2 * HALO) * (TW + 2 * HALO), NPQ = WT<T>::TH * TW;
+    const size_t lds = ((size_t)NPP * WT<T>::UC + (size_t)NPQ * WT<T>::VC) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(256), lds, s, a);
+    HS_LAUNCH_CHECK("conv_wgrad");
+    return HIPSEG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t hipseg_wgrad_workspace_elems(int mode, int CU, int CV, int B, int H, int W) {
+    size_t m = 0;
+    for (int dt = 0; dt < 2; ++dt) {
+        const Plan p = plan_for(dt, mode, CU, CV, B, H, W);
+        const size_t e = (size_t)p.S * p.NT * p.CUp * p.CVp;
+        if (e > m) m = e;
+    }
+    return m;
+}
+
+extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* p1, int CU1,
+                                 const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
+                                 hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_wgrad: bad dtype %d", dtype);
+    HS_REQUIRE(mode == HIPSEG_CONV3 || mode == HIPSEG_CONV1 || mode == HIPSEG_CONVT, "conv_wgrad: bad mode %d", mode);
+    HS_REQUIRE(p0 && q && dw && slabs && CU0 > 0 && CV > 0, "conv_wgrad: null operand or empty channel range");
+    HS_REQUIRE((CU1 == 0) == (p1 == nullptr), "conv_wgrad: p1/CU1 mismatch");
+    HS_REQUIRE(B > 0 && H > 0 && W > 0, "conv_wgrad: empty pixel grid");
+    const int CU = CU0 + CU1;
+    const Plan pl = plan_for(dtype, mode, CU, CV, B, H, W);
+    WgArgs a;
+    a.p0 = p0;
+    a.p1 = p1;
+    a.q = q;
+    a.slabs = slabs;
+    a.CU0 = CU0;
+    a.CU1 = CU1;
+    a.CU = CU;
+    a.CV = CV;
+    a.CUp = pl.CUp;
+    a.CVp = pl.CVp;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.ps = mode == HIPSEG_CONVT ? 2 : 1;
+    a.PH = a.ps * H;
+    a.PW = a.ps * W;
+    a.pa = 0;
+    a.pb = 0;
+    a.tiles_x = pl.tiles_x;
+    a.tiles_y = pl.tiles_y;
+    a.ntiles = pl.ntiles;
+    a.S = pl.S;
+    a.UT = pl.UT;
+    a.VT = pl.VT;
+    const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
+    a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
+    a.vec_ok_q = (CV % vec == 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)pl.NT * CU * CV;
+    const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int ntap_launch = mode == HIPSEG_CONVT ? 4 : 1;
+    for (int ab = 0; ab < ntap_launch; ++ab) {
+        a.pa = ab >> 1;
+        a.pb = ab & 1;
+        int rc;
+        if (dtype == HIPSEG_BF16)
+            rc = pl.NT == 9 ? launch<bf16, 9>(a, s) : launch<bf16, 1>(a, s);
+        else
+            rc = pl.NT == 9 ? launch<float, 9>(a, s) : launch<float, 1>(a, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slabs, dw, pl.S, pl.NT, CU, CV,
+                           pl.CUp, pl.CVp, mode, ab);
+        HS_LAUNCH_CHECK("wgrad_reduce");
+    }
+    return HIPSEG_OK;
+}

@@ -1,0 +1,104 @@
+// Error plumbing + weight packing (fp32 parameter layout -> MFMA operand layout).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void hipseg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* hipseg_last_error(void) { return g_err; }
+extern "C" int hipseg_abi_version(void) { return 1; }
+
+namespace {
+
+// packed layout [tap][Kp/G][Np][G]
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cout, int Cin, int ks,
+                                 int transpose, int Kp, int Np, int G, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        const int n = (int)((idx / G) % Np);
+        const int kg = (int)((idx / ((long)G * Np)) % (Kp / G));
+        const int tap = (int)(idx / ((long)Kp * Np));
+        const int k = kg * G + g;
+        const int ky = tap / ks, kx = tap % ks;
+        float v = 0.f;
+        if (!transpose) {  // K = Cin, N = Cout
+            if (k < Cin && n < Cout) v = w[(((long)n * Cin + k) * ks + ky) * ks + kx];
+        } else {  // K = Cout, N = Cin, taps flipped
+            if (k < Cout && n < Cin) v = w[(((long)k * Cin + n) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+        }
+        wp[idx] = (T)v;
+    }
+}
+
+// ConvTranspose2d weight (Cin, Cout, 2, 2)
+template <typename T>
+__global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int transpose,
+                                  int Kp, int Np, int G, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        const int n = (int)((idx / G) % Np);
+        const int kg = (int)((idx / ((long)G * Np)) % (Kp / G));
+        const int tap = (int)(idx / ((long)Kp * Np));
+        const int k = kg * G + g;
+        float v = 0.f;
+        if (!transpose) {  // forward: 1 tap, K = Cin, N = 4*Cout, n = ab*Cout + co
+            if (k < Cin && n < 4 * Cout) {
+                const int ab = n / Cout, co = n % Cout;
+                v = w[((long)k * Cout + co) * 4 + ab];
+            }
+        } else {  // data gradient: tap = ab, K = Cout, N = Cin
+            if (k < Cout && n < Cin) v = w[((long)n * Cout + k) * 4 + tap];
+        }
+        wp[idx] = (T)v;
+    }
+}
+
+inline int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int hipseg_pack_conv_weight(const float* w, void* wp, int dtype, int Cout, int Cin, int ksize,
+                                       int transpose, hipseg_stream_t stream) {
+    HS_REQUIRE(w && wp && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pack_conv_weight: bad arguments");
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_conv_weight: bad dtype");
+    const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+    const int Kp = hipseg_kpad(K, dtype), Np = hipseg_npad(N), G = dtype == HIPSEG_BF16 ? 8 : 1;
+    const long total = (long)ksize * ksize * Kp * Np;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(pack_conv_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16*)wp, Cout, Cin,
+                           ksize, transpose, Kp, Np, G, total);
+    else
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cout, Cin,
+                           ksize, transpose, Kp, Np, G, total);
+    HS_LAUNCH_CHECK("pack_conv_weight");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int Cin, int Cout, int transpose,
+                                        hipseg_stream_t stream) {
+    HS_REQUIRE(w && wp && Cout > 0 && Cin > 0, "pack_convT_weight: bad arguments");
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_convT_weight: bad dtype");
+    const int K = transpose ? Cout : Cin, N = transpose ? Cin : 4 * Cout, NT = transpose ? 4 : 1;
+    const int Kp = hipseg_kpad(K, dtype), Np = hipseg_npad(N), G = dtype == HIPSEG_BF16 ? 8 : 1;
+    const long total = (long)NT * Kp * Np;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(pack_convT_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16*)wp, Cin, Cout,
+                           transpose, Kp, Np, G, total);
+    else
+        hipLaunchKernelGGL(pack_convT_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cin, Cout,
+                           transpose, Kp, Np, G, total);
+    HS_LAUNCH_CHECK("pack_convT_weight");
+    return HIPSEG_OK;
+}

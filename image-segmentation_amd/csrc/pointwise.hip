@@ -1,0 +1,563 @@
+// 1x1 stem / head, align-corners bilinear resize and layout helpers (all HBM-bound), NHWC.
+#include "common.h"
+
+namespace {
+
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+    if constexpr (V == 1) {
+        v[0] = (float)p[0];
+    } else {
+        const typename VecOf<T>::type t = *reinterpret_cast<const typename VecOf<T>::type*>(p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = (float)t[e];
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+    if constexpr (V == 1) {
+        p[0] = (T)v[0];
+    } else {
+        typename VecOf<T>::type t;
+#pragma unroll
+        for (int e = 0; e < V; ++e) t[e] = (T)v[e];
+        *reinterpret_cast<typename VecOf<T>::type*>(p) = t;
+    }
+}
+inline int vec_for(int C, int dtype) {
+    const int v = dtype == HIPSEG_BF16 ? 8 : 4;
+    return (C % v == 0) ? v : 1;
+}
+inline unsigned grid_for(long total, int cap = 4096) {
+    long g = (total + 255) / 256;
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+constexpr int MAXCIN = 4;  // stem: RGB(A) images
+
+// ------------------------------------------------------------------ stem: NCHW fp32 image -> NHWC
+template <typename T, int V>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* __restrict__ y, int B, int Cin,
+                                                        long HW, int Cout) {
+    const int CG = Cout / V;
+    const long total = (long)B * HW * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const long p = i / CG;  // n*HW + pixel
+        const long n = p / HW, hw = p % HW;
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = b[cg * V + e];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = x[(n * Cin + ci) * HW + hw];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = fmaf(w[(cg * V + e) * Cin + ci], xv, o[e]);
+        }
+        stv<T, V>(y + p * Cout + cg * V, o);
+    }
+}
+
+// partial[blk][Cin+1][Cout]: rows 0..Cin-1 = sum dy*x_ci, row Cin = sum dy
+template <typename T, int V>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                        float* __restrict__ partial, int B, int Cin, long HW, int Cout,
+                                                        int CG, int PL, long ppb) {
+    __shared__ float red[2048];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    float acc[MAXCIN + 1][V];
+#pragma unroll
+    for (int r = 0; r <= MAXCIN; ++r)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[r][e] = 0.f;
+    const long npix = (long)B * HW;
+    if (pl < PL) {
+        const long start = blockIdx.x * ppb;
+        long end = start + ppb;
+        if (end > npix) end = npix;
+        for (long p = start + pl; p < end; p += PL) {
+            const long n = p / HW, hw = p % HW;
+            float g[V];
+            ldv<T, V>(dy + p * Cout + cg * V, g);
+#pragma unroll
+            for (int ci = 0; ci < MAXCIN; ++ci) {
+                if (ci < Cin) {
+                    const float xv = x[(n * Cin + ci) * HW + hw];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[ci][e] = fmaf(g[e], xv, acc[ci][e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[MAXCIN][e] += g[e];
+        }
+    }
+    const int R = 2048 / Cout;
+#pragma unroll
+    for (int r = 0; r <= MAXCIN; ++r) {
+        if (r < Cin || r == MAXCIN) {
+            float t[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) t[e] = 0.f;
+            for (int base = 0; base < PL; base += R) {
+                __syncthreads();
+                if (pl >= base && pl < base + R && pl < PL) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) red[(pl - base) * Cout + cg * V + e] = acc[r][e];
+                }
+                __syncthreads();
+                if (pl == 0) {
+                    const int lim = (PL - base) < R ? (PL - base) : R;
+                    for (int j = 0; j < lim; ++j)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) t[e] += red[j * Cout + cg * V + e];
+                }
+            }
+            if (pl == 0) {
+                const int row = r == MAXCIN ? Cin : r;
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    partial[((size_t)blockIdx.x * (Cin + 1) + row) * Cout + cg * V + e] = t[e];
+            }
+        }
+    }
+}
+
+// dw[co][ci], db[co] from partial[blk][Cin+1][Cout]
+__global__ void stem_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin, int Cout,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (Cin + 1) * Cout) return;
+    const int row = i / Cout, co = i % Cout;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * (Cin + 1) + row) * Cout + co];
+    if (row < Cin)
+        dw[co * Cin + row] = s;
+    else
+        db[co] = s;
+}
+
+// ------------------------------------------------------------------ head: NHWC -> NCHW fp32 logits
+constexpr int MAXHC = 8;  // head output channels
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ logits, int B,
+                                                        long HW, int Cin, int Cout) {
+    const long npix = (long)B * HW;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        float o[MAXHC];
+#pragma unroll
+        for (int co = 0; co < MAXHC; ++co) o[co] = co < Cout ? b[co] : 0.f;
+        for (int c = 0; c < Cin; c += V) {
+            float v[V];
+            ldv<T, V>(x + p * Cin + c, v);
+#pragma unroll
+            for (int co = 0; co < MAXHC; ++co)
+                if (co < Cout) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[co] = fmaf(w[co * Cin + c + e], v[e], o[co]);
+                }
+        }
+        const long n = p / HW, hw = p % HW;
+#pragma unroll
+        for (int co = 0; co < MAXHC; ++co)
+            if (co < Cout) logits[(n * Cout + co) * HW + hw] = o[co];
+    }
+}
+
+// dx[p][c] = sum_co dl[co][p] w[co][c];  partial[blk][Cout][Cin+1]: dW rows, last column = db
+template <typename T, int V>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dl,
+                                                        const float* __restrict__ w, T* __restrict__ dx,
+                                                        float* __restrict__ partial, int B, long HW, int Cin, int Cout,
+                                                        int CG, int PL, long ppb) {
+    __shared__ float red[2048];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    float aw[MAXHC][V], ab[MAXHC];
+#pragma unroll
+    for (int co = 0; co < MAXHC; ++co) {
+        ab[co] = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) aw[co][e] = 0.f;
+    }
+    const long npix = (long)B * HW;
+    if (pl < PL) {
+        float wv[MAXHC][V];
+#pragma unroll
+        for (int co = 0; co < MAXHC; ++co)
+#pragma unroll
+            for (int e = 0; e < V; ++e) wv[co][e] = co < Cout ? w[co * Cin + cg * V + e] : 0.f;
+        const long start = blockIdx.x * ppb;
+        long end = start + ppb;
+        if (end > npix) end = npix;
+        for (long p = start + pl; p < end; p += PL) {
+            const long n = p / HW, hw = p % HW;
+            float xv[V], o[V];
+            ldv<T, V>(x + p * Cin + cg * V, xv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int co = 0; co < MAXHC; ++co)
+                if (co < Cout) {
+                    const float g = dl[(n * Cout + co) * HW + hw];
+                    ab[co] += g;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        o[e] = fmaf(g, wv[co][e], o[e]);
+                        aw[co][e] = fmaf(g, xv[e], aw[co][e]);
+                    }
+                }
+            stv<T, V>(dx + p * Cin + cg * V, o);
+        }
+    }
+    const int R = 2048 / (Cin + 1);
+#pragma unroll
+    for (int co = 0; co < MAXHC; ++co) {
+        if (co < Cout) {
+            float t[V], tb = 0.f;
+#pragma unroll
+            for (int e = 0; e < V; ++e) t[e] = 0.f;
+            for (int base = 0; base < PL; base += R) {
+                __syncthreads();
+                if (pl >= base && pl < base + R && pl < PL) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) red[(pl - base) * (Cin + 1) + cg * V + e] = aw[co][e];
+                    if (cg == 0) red[(pl - base) * (Cin + 1) + Cin] = ab[co];
+                }
+                __syncthreads();
+                if (pl == 0) {
+                    const int lim = (PL - base) < R ? (PL - base) : R;
+                    for (int j = 0; j < lim; ++j) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) t[e] += red[j * (Cin + 1) + cg * V + e];
+                        if (cg == 0) tb += red[j * (Cin + 1) + Cin];
+                    }
+                }
+            }
+            if (pl == 0) {
+                float* dst = partial + ((size_t)blockIdx.x * Cout + co) * (Cin + 1);
+#pragma unroll
+                for (int e = 0; e < V; ++e) dst[cg * V + e] = t[e];
+                if (cg == 0) dst[Cin] = tb;
+            }
+        }
+    }
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin, int Cout,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * (Cin + 1)) return;
+    const int co = i / (Cin + 1), c = i % (Cin + 1);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * Cout * (Cin + 1) + i];
+    if (c < Cin)
+        dw[co * Cin + c] = s;
+    else
+        db[co] = s;
+}
+
+// ------------------------------------------------------------------ bilinear, align_corners=True
+// index/lambda exactly as ATen's area_pixel_compute_source_index + guard_index_and_lambda (fp32).
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    const float real = scale * (float)dst;
+    i0 = (int)real;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float lam = real - (float)i0;
+    lam = fminf(fmaxf(lam, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = lam;
+    l0 = 1.f - lam;
+}
+__host__ __device__ __forceinline__ float ac_scale(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi,
+                                                            int Wi, int Ho, int Wo, int C, float sy, float sx) {
+    const int CG = C / V;
+    const long total = (long)B * Ho * Wo * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const long op = i / CG;
+        const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho);
+        const long n = op / ((long)Wo * Ho);
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        src_index(sy, oy, Hi, y0, y1, wy0, wy1);
+        src_index(sx, ox, Wi, x0, x1, wx0, wx1);
+        float a[V], b[V], c[V], d[V], o[V];
+        ldv<T, V>(x + ((n * Hi + y0) * Wi + x0) * C + cg * V, a);
+        ldv<T, V>(x + ((n * Hi + y0) * Wi + x1) * C + cg * V, b);
+        ldv<T, V>(x + ((n * Hi + y1) * Wi + x0) * C + cg * V, c);
+        ldv<T, V>(x + ((n * Hi + y1) * Wi + x1) * C + cg * V, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = wy0 * (wx0 * a[e] + wx1 * b[e]) + wy1 * (wx0 * c[e] + wx1 * d[e]);
+        stv<T, V>(y + op * C + cg * V, o);
+    }
+}
+
+// gather form of the adjoint: each INPUT pixel sums the output pixels that sampled it (deterministic)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi,
+                                                            int Wi, int Ho, int Wo, int C, float sy, float sx) {
+    const int CG = C / V;
+    const long total = (long)B * Hi * Wi * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const long ip = i / CG;
+        const int ix = (int)(ip % Wi), iy = (int)((ip / Wi) % Hi);
+        const long n = ip / ((long)Wi * Hi);
+        int jy0 = 0, jy1 = Ho - 1, jx0 = 0, jx1 = Wo - 1;
+        if (sy > 0.f) {
+            jy0 = max(0, (int)floorf((float)(iy - 1) / sy) - 1);
+            jy1 = min(Ho - 1, (int)ceilf((float)(iy + 1) / sy) + 1);
+        }
+        if (sx > 0.f) {
+            jx0 = max(0, (int)floorf((float)(ix - 1) / sx) - 1);
+            jx1 = min(Wo - 1, (int)ceilf((float)(ix + 1) / sx) + 1);
+        }
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int jy = jy0; jy <= jy1; ++jy) {
+            int a0, a1;
+            float l0, l1;
+            src_index(sy, jy, Hi, a0, a1, l0, l1);
+            const float wy = (a0 == iy ? l0 : 0.f) + (a1 == iy ? l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int jx = jx0; jx <= jx1; ++jx) {
+                int b0, b1;
+                float m0, m1;
+                src_index(sx, jx, Wi, b0, b1, m0, m1);
+                const float wx = (b0 == ix ? m0 : 0.f) + (b1 == ix ? m1 : 0.f);
+                if (wx == 0.f) continue;
+                float g[V];
+                ldv<T, V>(dy + ((n * Ho + jy) * Wo + jx) * C + cg * V, g);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(wy * wx, g[e], acc[e]);
+            }
+        }
+        stv<T, V>(dx + ip * C + cg * V, acc);
+    }
+}
+
+// ------------------------------------------------------------------ layout helpers
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, long HW) {
+    const long total = (long)B * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const long n = p / HW, hw = p % HW;
+        y[i] = (T)x[(n * C + c) * HW + hw];
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, long HW) {
+    const long total = (long)B * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long n = i / (HW * C);
+        y[i] = (float)x[(n * HW + hw) * C + c];
+    }
+}
+
+struct RedGeo {
+    int CG, PL, nblk;
+    long ppb;
+};
+inline RedGeo red_geo(long npix, int C, int V) {
+    RedGeo g;
+    g.CG = C / V;
+    g.PL = 256 / g.CG;
+    long nb = (npix + (long)g.PL * 8 - 1) / ((long)g.PL * 8);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    g.nblk = (int)nb;
+    g.ppb = (npix + nb - 1) / nb;
+    return g;
+}
+
+#define DISPATCH_TV(dtype, V, ...)  \
+    do {                            \
+        if (dtype == HIPSEG_BF16) { \
+            typedef bf16 T_;        \
+            if (V == 8) {           \
+                constexpr int V_ = 8; \
+                __VA_ARGS__         \
+            } else {                \
+                constexpr int V_ = 1; \
+                __VA_ARGS__         \
+            }                       \
+        } else {                    \
+            typedef float T_;       \
+            if (V == 4) {           \
+                constexpr int V_ = 4; \
+                __VA_ARGS__         \
+            } else {                \
+                constexpr int V_ = 1; \
+                __VA_ARGS__         \
+            }                       \
+        }                           \
+    } while (0)
+
+}  // namespace
+
+extern "C" int hipseg_stem_fwd(int dtype, const float* x, const float* w, const float* b, void* y, int B, int Cin,
+                               int H, int W, int Cout, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "stem_fwd: bad dtype");
+    HS_REQUIRE(x && w && b && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "stem_fwd: bad arguments");
+    const int V = vec_for(Cout, dtype);
+    const long HW = (long)H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((stem_fwd_kernel<T_, V_>), dim3(grid_for(B * HW * (Cout / V_))), dim3(256), 0, s, x, w, b,
+                           (T_*)y, B, Cin, HW, Cout);
+    });
+    HS_LAUNCH_CHECK("stem_fwd");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_stem_bwd_blocks(int B, int H, int W) {
+    long nb = ((long)B * H * W + 255) / 256;
+    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+}
+
+extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float* partial, float* dw, float* db, int B,
+                               int Cin, int H, int W, int Cout, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "stem_bwd: bad dtype");
+    HS_REQUIRE(x && dy && partial && dw && db && B > 0 && H > 0 && W > 0, "stem_bwd: bad arguments");
+    HS_REQUIRE(Cin >= 1 && Cin <= MAXCIN, "stem_bwd: in_channels %d unsupported (1..%d)", Cin, MAXCIN);
+    const int V = vec_for(Cout, dtype);
+    HS_REQUIRE(Cout / V <= 256 && Cout <= 2048, "stem_bwd: unsupported Cout %d", Cout);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    RedGeo g;
+    g.CG = Cout / V;
+    g.PL = 256 / g.CG;
+    g.nblk = hipseg_stem_bwd_blocks(B, H, W);
+    g.ppb = (npix + g.nblk - 1) / g.nblk;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((stem_bwd_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, x, (const T_*)dy, partial, B, Cin,
+                           HW, Cout, g.CG, g.PL, g.ppb);
+    });
+    HS_LAUNCH_CHECK("stem_bwd");
+    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(cdiv((Cin + 1) * Cout, 256)), dim3(256), 0, s, partial, g.nblk,
+                       Cin, Cout, dw, db);
+    HS_LAUNCH_CHECK("stem_bwd_finalize");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int B, int H,
+                               int W, int Cin, int Cout, hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "head_fwd: bad dtype");
+    HS_REQUIRE(x && w && b && logits && B > 0 && H > 0 && W > 0 && Cin > 0, "head_fwd: bad arguments");
+    HS_REQUIRE(Cout >= 1 && Cout <= MAXHC, "head_fwd: out_channels %d unsupported (1..%d)", Cout, MAXHC);
+    const int V = vec_for(Cin, dtype);
+    const long HW = (long)H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((head_fwd_kernel<T_, V_>), dim3(grid_for(B * HW)), dim3(256), 0, s, (const T_*)x, w, b,
+                           logits, B, HW, Cin, Cout);
+    });
+    HS_LAUNCH_CHECK("head_fwd");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_head_bwd_blocks(int B, int H, int W) {
+    long nb = ((long)B * H * W + 255) / 256;
+    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+}
+
+extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, const float* w, void* dx,
+                               float* partial, float* dw, float* db, int B, int H, int W, int Cin, int Cout,
+                               hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "head_bwd: bad dtype");
+    HS_REQUIRE(x && dlogits && w && dx && partial && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+    HS_REQUIRE(Cout >= 1 && Cout <= MAXHC, "head_bwd: out_channels %d unsupported (1..%d)", Cout, MAXHC);
+    const int V = vec_for(Cin, dtype);
+    HS_REQUIRE(Cin / V <= 256 && Cin + 1 <= 2048, "head_bwd: unsupported Cin %d", Cin);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    RedGeo g;
+    g.CG = Cin / V;
+    g.PL = 256 / g.CG;
+    g.nblk = hipseg_head_bwd_blocks(B, H, W);
+    g.ppb = (npix + g.nblk - 1) / g.nblk;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((head_bwd_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, (const T_*)x, dlogits, w, (T_*)dx,
+                           partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb);
+    });
+    HS_LAUNCH_CHECK("head_bwd");
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, s, partial, g.nblk,
+                       Cin, Cout, dw, db);
+    HS_LAUNCH_CHECK("head_bwd_finalize");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                   hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bilinear_fwd: bad dtype");
+    HS_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad arguments");
+    const int V = vec_for(C, dtype);
+    const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((bilinear_fwd_kernel<T_, V_>), dim3(grid_for((long)B * Ho * Wo * (C / V_))), dim3(256), 0,
+                           s, (const T_*)x, (T_*)y, B, Hi, Wi, Ho, Wo, C, sy, sx);
+    });
+    HS_LAUNCH_CHECK("bilinear_fwd");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                   hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bilinear_bwd: bad dtype");
+    HS_REQUIRE(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad arguments");
+    const int V = vec_for(C, dtype);
+    const float sy = ac_scale(Hi, Ho), sx = ac_scale(Wi, Wo);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((bilinear_bwd_kernel<T_, V_>), dim3(grid_for((long)B * Hi * Wi * (C / V_))), dim3(256), 0,
+                           s, (const T_*)dy, (T_*)dx, B, Hi, Wi, Ho, Wo, C, sy, sx);
+    });
+    HS_LAUNCH_CHECK("bilinear_bwd");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W,
+                                   hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "nchw_to_nhwc: bad dtype");
+    HS_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
+    const long HW = (long)H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(grid_for(B * HW * C)), dim3(256), 0, s, x, (bf16*)y, B, C,
+                           HW);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(B * HW * C)), dim3(256), 0, s, x, (float*)y, B, C,
+                           HW);
+    HS_LAUNCH_CHECK("nchw_to_nhwc");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W,
+                                   hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "nhwc_to_nchw: bad dtype");
+    HS_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
+    const long HW = (long)H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(grid_for(B * HW * C)), dim3(256), 0, s, (const bf16*)x, y,
+                           B, C, HW);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(B * HW * C)), dim3(256), 0, s, (const float*)x, y,
+                           B, C, HW);
+    HS_LAUNCH_CHECK("nhwc_to_nchw");
+    return HIPSEG_OK;
+}

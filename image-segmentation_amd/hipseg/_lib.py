@@ -1,0 +1,100 @@
+"""ctypes binding of libhipseg.so -- the C ABI declared in include/hipseg.h.
+
+The product path has NO CPU fallback: if the library is missing or fails to load,
+importing this module raises, and every op raises RuntimeError on a non-zero return.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhipseg.so")
+
+F32, BF16 = 0, 1
+CONV3, CONV1, CONV2S2, CONVT = 0, 1, 2, 3
+
+P = c_void_p
+I = c_int
+L = c_long
+
+# name -> (restype, argtypes); mirrors include/hipseg.h line by line
+PROTOTYPES = {
+    "hipseg_last_error": (c_char_p, []),
+    "hipseg_abi_version": (I, []),
+    "hipseg_kpad": (I, [I, I]),
+    "hipseg_npad": (I, [I]),
+    "hipseg_conv_mtiles": (I, [I, I, I]),
+    "hipseg_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
+    "hipseg_pack_convT_weight": (I, [P, P, I, I, I, I, P]),
+    "hipseg_conv_igemm": (I, [I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, P]),
+    "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
+    "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),
+    "hipseg_bn_finalize": (I, [P, I, I, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
+    "hipseg_bn_eval_params": (I, [P, P, P, P, c_float, I, P, P, P, P, P]),
+    "hipseg_bn_relu_apply": (I, [I, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_bn_bwd_blocks": (I, [I, I, I, I, I, I]),
+    "hipseg_bn_bwd_reduce": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_bn_bwd_apply": (I, [I, P, P, P, P, P, P, P, c_double, I, P, P, I, I, I, I, I, P]),
+    "hipseg_colsum_finalize": (I, [P, I, I, I, P, P]),
+    "hipseg_colsum_blocks": (I, [L, I, I]),
+    "hipseg_colsum": (I, [I, P, L, I, P, P, P]),
+    "hipseg_stem_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_stem_bwd_blocks": (I, [I, I, I]),
+    "hipseg_stem_bwd": (I, [I, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_head_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_head_bwd_blocks": (I, [I, I, I]),
+    "hipseg_head_bwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_bilinear_fwd": (I, [I, P, P, I, I, I, I, I, I, P]),
+    "hipseg_bilinear_bwd": (I, [I, P, P, I, I, I, I, I, I, P]),
+    "hipseg_loss_blocks": (I, [L]),
+    "hipseg_ce_fwd": (I, [P, P, P, P, I, I, L, P]),
+    "hipseg_ce_bwd": (I, [P, P, P, P, P, I, I, L, P]),
+    "hipseg_bce_dice_fwd": (I, [P, P, P, P, P, L, P]),
+    "hipseg_bce_dice_bwd": (I, [P, P, P, P, P, L, P]),
+    "hipseg_confusion": (I, [P, P, P, I, I, L, P]),
+    "hipseg_nchw_to_nhwc": (I, [I, P, P, I, I, I, I, P]),
+    "hipseg_nhwc_to_nchw": (I, [I, P, P, I, I, I, I, P]),
+}
+
+# functions whose int return value is a geometry answer, not a status code
+_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_bn_bwd_blocks",
+         "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
+         "hipseg_wgrad_workspace_elems", "hipseg_last_error"}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "The HIP path has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class HipsegError(RuntimeError):
+    pass
+
+
+def _wrap(name):
+    fn = getattr(lib, name)
+    if name in _PURE:
+        return fn
+
+    def call(*a):
+        rc = fn(*a)
+        if rc != 0:
+            raise HipsegError(f"{name} failed (rc={rc}): {lib.hipseg_last_error().decode()}")
+
+    call.__name__ = name
+    return call
+
+
+for _n in PROTOTYPES:
+    globals()[_n[len("hipseg_"):]] = _wrap(_n)

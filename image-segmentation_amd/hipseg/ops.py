@@ -1,0 +1,389 @@
+"""torch.autograd.Function wrappers over the C ABI (include/hipseg.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and the
+autograd tape.  Every numerical step runs in libhipseg.so.  Activations are NHWC in HBM and are
+handed around as logical-NCHW tensors with channels_last strides, so module signatures keep the
+reference's (B, C, H, W) shapes.
+"""
+import contextlib
+import os
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+_FORCED = [os.environ.get("HIPSEG_PRECISION", "auto").lower()]
+
+
+def precision():
+    """'bf16' or 'fp32'.  auto: bf16 under torch.autocast (the reference's wrappers train under
+    autocast, models/model_wrappers.py:170), fp32 otherwise (TestWrapper, model_wrappers.py:383)."""
+    f = _FORCED[0]
+    if f in ("bf16", "fp32"):
+        return f
+    return "bf16" if torch.is_autocast_enabled() else "fp32"
+
+
+@contextlib.contextmanager
+def precision_mode(p):
+    assert p in ("auto", "bf16", "fp32")
+    old, _FORCED[0] = _FORCED[0], p
+    try:
+        yield
+    finally:
+        _FORCED[0] = old
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    if t.dtype == torch.float32:
+        return L.F32
+    raise TypeError(f"hipseg: unsupported activation dtype {t.dtype}")
+
+
+def _tdtype(prec):
+    return torch.bfloat16 if prec == "bf16" else torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("hipseg: the HIP path needs CUDA/HIP tensors (no CPU fallback); got a CPU tensor")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def nhwc_empty(B, C, H, W, dtype, device):
+    """logical (B,C,H,W) tensor whose storage is dense NHWC."""
+    return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc(t):
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def as_nhwc(t, dtype):
+    """dense-NHWC view/copy of a logical NCHW tensor in `dtype` (layout plumbing at block boundaries)."""
+    _require_gpu(t)
+    if t.dtype == dtype and is_nhwc(t):
+        return t
+    return t.to(dtype).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def _pack_conv(w, dt, transpose):
+    cout, cin, k, _ = w.shape
+    K, N = (cout, cin) if transpose else (cin, cout)
+    n = k * k * L.kpad(K, dt) * L.npad(N)
+    wp = torch.empty(n, dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=w.device)
+    L.pack_conv_weight(ptr(w), ptr(wp), dt, cout, cin, k, int(transpose), _stream())
+    return wp
+
+
+def _pack_convT(w, dt, transpose):
+    cin, cout = w.shape[0], w.shape[1]
+    if transpose:
+        n = 4 * L.kpad(cout, dt) * L.npad(cin)
+    else:
+        n = L.kpad(cin, dt) * L.npad(4 * cout)
+    wp = torch.empty(n, dtype=torch.bfloat16 if dt == L.BF16 else torch.float32, device=w.device)
+    L.pack_convT_weight(ptr(w), ptr(wp), dt, cin, cout, int(transpose), _stream())
+    return wp
+
+
+def _wgrad(dt, mode, p0, p1, q, dw, B, H, W):
+    cu0 = p0.shape[1]
+    cu1 = p1.shape[1] if p1 is not None else 0
+    cv = q.shape[1]
+    slabs = _f32(L.wgrad_workspace_elems(mode, cu0 + cu1, cv, B, H, W), dw.device)
+    L.conv_wgrad(dt, mode, ptr(p0), cu0, ptr(p1), cu1, ptr(q), cv, ptr(dw), ptr(slabs), B, H, W, _stream())
+
+
+class _BN:
+    """per-layer BatchNorm state of one forward (device vectors of length C)."""
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, C, device):
+        v = _f32(4 * C, device)
+        self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
+
+
+def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool):
+    """conv3x3 (+bias, +BN batch statistics in the epilogue) -> BN finalize -> BN-apply+ReLU(+pool).
+    Returns (raw conv output, activated output, bn state)."""
+    B, _, H, W = x0.shape
+    cout = w.shape[0]
+    dev = x0.device
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    wp = _pack_conv(w, dt, False)
+    raw = nhwc_empty(B, cout, H, W, x0.dtype, dev)
+    bn = _BN(cout, dev)
+    s = _stream()
+    if train:
+        mt = L.conv_mtiles(B, H, W)
+        stats = _f32(mt * 2 * cout, dev)
+        L.conv_igemm(dt, L.CONV3, ptr(x0), c0, ptr(x1), c1, ptr(wp), ptr(b), ptr(raw), cout, 0, 0, ptr(stats), B, H, W, s)
+        L.bn_finalize(ptr(stats), mt, cout, float(B * H * W), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm), ptr(rv),
+                      ptr(nbt), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), s)
+    else:
+        L.conv_igemm(dt, L.CONV3, ptr(x0), c0, ptr(x1), c1, ptr(wp), ptr(b), ptr(raw), cout, 0, 0, 0, B, H, W, s)
+        L.bn_eval_params(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, cout, ptr(bn.mean), ptr(bn.invstd),
+                         ptr(bn.scale), ptr(bn.shift), s)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    act = nhwc_empty(B, cout, Ho, Wo, x0.dtype, dev)
+    L.bn_relu_apply(dt, ptr(raw), ptr(bn.scale), ptr(bn.shift), ptr(act), B, H, W, cout, int(pool), s)
+    return raw, act, bn
+
+
+def _bn_relu_bwd(dt, dy, raw, bn, train, pool):
+    """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv)."""
+    B, C, H, W = raw.shape
+    dev = raw.device
+    s = _stream()
+    nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
+    partial = _f32(nblk * 2 * C, dev)
+    sums = _f32(2 * C, dev)
+    L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
+                    B, H, W, C, int(pool), s)
+    L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), s)
+    draw = nhwc_empty(B, C, H, W, raw.dtype, dev)
+    dbias = torch.zeros(C, dtype=torch.float32, device=dev)
+    L.bn_bwd_apply(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
+                   float(B * H * W), 0 if train else 1, ptr(draw), ptr(dbias), B, H, W, C, int(pool), s)
+    return draw, sums[C:], sums[:C], dbias
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """[cat(x0,x1)] -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU [-> MaxPool2d(2,2)]
+    = ConvBlock / ConvBlockDownsample / the conv half of ConvBlockUpsampleSkip
+    (models/processing_blocks.py:40-52, 69-77, 108-109)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool):
+        dt = _dt(x0)
+        raw1, a1, bn1 = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False)
+        raw2, out, bn2 = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool)
+        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2)
+        ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, x1, w1, w2, raw1, a1, raw2 = ctx.saved_tensors
+        dt, train, pool = ctx.dt, ctx.train, ctx.pool
+        B, C, H, W = raw2.shape
+        dev = raw2.device
+        s = _stream()
+        dout = as_nhwc(dout, raw2.dtype)
+        # ---- second conv layer
+        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool)
+        dw2 = torch.empty_like(w2)
+        _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
+        wp2t = _pack_conv(w2, dt, True)
+        da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
+        L.conv_igemm(dt, L.CONV3, ptr(draw2), C, 0, 0, ptr(wp2t), 0, ptr(da1), C, 0, 0, 0, B, H, W, s)
+        # ---- first conv layer
+        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False)
+        dw1 = torch.empty_like(w1)
+        _wgrad(dt, L.CONV3, x0, x1, draw1, dw1, B, H, W)
+        dx0 = dx1 = None
+        need0 = ctx.needs_input_grad[0]
+        need1 = x1 is not None and ctx.needs_input_grad[1]
+        if need0 or need1:
+            c0 = x0.shape[1]
+            c1 = x1.shape[1] if x1 is not None else 0
+            wp1t = _pack_conv(w1, dt, True)
+            dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
+            dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
+            L.conv_igemm(dt, L.CONV3, ptr(draw1), C, 0, 0, ptr(wp1t), 0, ptr(dx0), c0, ptr(dx1), c1, 0, B, H, W, s)
+        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None)
+
+
+class ConvT2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (models/processing_blocks.py:102,128)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dt = _dt(x)
+        B, cin, H, W = x.shape
+        cout = w.shape[1]
+        wp = _pack_convT(w, dt, False)
+        y = nhwc_empty(B, cout, 2 * H, 2 * W, x.dtype, x.device)
+        L.conv_igemm(dt, L.CONVT, ptr(x), cin, 0, 0, ptr(wp), ptr(b), ptr(y), cout, 0, 0, 0, B, H, W, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.dt = dt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dt = ctx.dt
+        B, cin, H, W = x.shape
+        cout = w.shape[1]
+        dev = x.device
+        s = _stream()
+        dy = as_nhwc(dy, x.dtype)
+        dw = torch.empty_like(w)
+        _wgrad(dt, L.CONVT, dy, None, x, dw, B, H, W)
+        npix = B * 4 * H * W
+        part = _f32(L.colsum_blocks(npix, cout, dt) * cout, dev)
+        db = _f32(cout, dev)
+        L.colsum(dt, ptr(dy), npix, cout, ptr(part), ptr(db), s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpt = _pack_convT(w, dt, True)
+            dx = nhwc_empty(B, cin, H, W, x.dtype, dev)
+            L.conv_igemm(dt, L.CONV2S2, ptr(dy), cout, 0, 0, ptr(wpt), 0, ptr(dx), cin, 0, 0, 0, B, H, W, s)
+        return dx, dw, db
+
+
+class BilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) (models/processing_blocks.py:107)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        dt = _dt(x)
+        B, C, Hi, Wi = x.shape
+        y = nhwc_empty(B, C, Ho, Wo, x.dtype, x.device)
+        L.bilinear_fwd(dt, ptr(x), ptr(y), B, Hi, Wi, Ho, Wo, C, _stream())
+        ctx.geo = (dt, B, C, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dt, B, C, Hi, Wi, Ho, Wo = ctx.geo
+        dy = as_nhwc(dy, _tdtype("bf16" if dt == L.BF16 else "fp32"))
+        dx = nhwc_empty(B, C, Hi, Wi, dy.dtype, dy.device)
+        L.bilinear_bwd(dt, ptr(dy), ptr(dx), B, Hi, Wi, Ho, Wo, C, _stream())
+        return dx, None, None
+
+
+class StemFn(torch.autograd.Function):
+    """1x1 stem conv on the NCHW fp32 image -> NHWC activations (models/UNet.py:39,62)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, prec):
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        td = _tdtype(prec)
+        dt = L.BF16 if prec == "bf16" else L.F32
+        y = nhwc_empty(B, cout, H, W, td, x.device)
+        L.stem_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(y), B, cin, H, W, cout, _stream())
+        ctx.save_for_backward(x)
+        ctx.dt, ctx.wshape = dt, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("hipseg: gradient w.r.t. the input image is not part of the training hot path")
+        (x,) = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = ctx.wshape[0]
+        dy = as_nhwc(dy, _tdtype("bf16" if ctx.dt == L.BF16 else "fp32"))
+        nblk = L.stem_bwd_blocks(B, H, W)
+        part = _f32(nblk * (cin + 1) * cout, x.device)
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
+        db = _f32(cout, x.device)
+        L.stem_bwd(ctx.dt, ptr(x), ptr(dy), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
+        return None, dw, db, None
+
+
+class HeadFn(torch.autograd.Function):
+    """1x1 head conv NHWC -> NCHW fp32 logits (models/UNet.py:55,73)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dt = _dt(x)
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        logits = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+        L.head_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(logits), B, H, W, cin, cout, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.dt = dt
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, w = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dl = dl.float().contiguous()
+        nblk = L.head_bwd_blocks(B, H, W)
+        part = _f32(nblk * cout * (cin + 1), x.device)
+        dx = nhwc_empty(B, cin, H, W, x.dtype, x.device)
+        dw = torch.empty_like(w)
+        db = _f32(cout, x.device)
+        L.head_bwd(ctx.dt, ptr(x), ptr(dl), ptr(w), ptr(dx), ptr(part), ptr(dw), ptr(db), B, H, W, cin, cout, _stream())
+        return dx, dw, db
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(pred, target) = HybridLoss.forward (models/losses.py:13-15)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        part = _f32(L.loss_blocks(B * HW) * 2, logits.device)
+        loss = _f32(2, logits.device)
+        L.ce_fwd(ptr(logits), ptr(target), ptr(part), ptr(loss), B, C, HW, _stream())
+        ctx.save_for_backward(logits, target, loss)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, loss = ctx.saved_tensors
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        gs = g.reshape(1).float().contiguous()
+        dl = torch.empty_like(logits)
+        L.ce_bwd(ptr(logits), ptr(target), ptr(gs), ptr(loss), ptr(dl), B, C, HW, _stream())
+        return dl, None
+
+
+class BceDiceFn(torch.autograd.Function):
+    """BCEWithLogitsLoss + smp DiceLoss(binary) on sigmoid(pred) = HybridLossBinary.forward
+    (models/losses.py:24-36)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        n = logits.numel()
+        part = _f32(L.loss_blocks(n) * 4, logits.device)
+        sums = _f32(4, logits.device)
+        loss = _f32(1, logits.device)
+        L.bce_dice_fwd(ptr(logits), ptr(target), ptr(part), ptr(sums), ptr(loss), n, _stream())
+        ctx.save_for_backward(logits, target, sums)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, sums = ctx.saved_tensors
+        gs = g.reshape(1).float().contiguous()
+        dl = torch.empty_like(logits)
+        L.bce_dice_bwd(ptr(logits), ptr(target), ptr(sums), ptr(gs), ptr(dl), logits.numel(), _stream())
+        return dl, None
+
+
+def confusion_matrix(logits, target):
+    """CxC int64 counts conf[t, p] of argmax(logits) vs target (metrics, models/losses.py:38-63,129-154)."""
+    _require_gpu(logits)
+    logits = logits.float().contiguous()
+    target = target.long().contiguous()
+    B, C = logits.shape[0], logits.shape[1]
+    conf = torch.empty((C, C), dtype=torch.int64, device=logits.device)
+    L.confusion(ptr(logits), ptr(target), ptr(conf), B, C, logits[0, 0].numel(), _stream())
+    return conf

@@ -1,0 +1,71 @@
+"""UNet / LargeUNet with the reference's API and state_dict (reference: models/UNet.py)."""
+import torch
+import torch.nn as nn
+
+from hipseg import ops
+from models.processing_blocks import ConvBlock, ConvBlockDownsample, ConvBlockUpsampleSkip
+
+__all__ = ["UNet", "LargeUNet"]
+
+
+def _stem(conv, x):
+    """1x1 stem on the NCHW image -> NHWC activations in the active precision."""
+    ops._require_gpu(x)
+    if x.shape[1] != conv.in_channels:
+        raise ValueError(f"expected {conv.in_channels} input channels, got {x.shape[1]}")
+    return ops.StemFn.apply(x.float().contiguous(), conv.weight, conv.bias, ops.precision())
+
+
+def _head(conv, x):
+    return ops.HeadFn.apply(x, conv.weight, conv.bias)
+
+
+class _UNetBase(nn.Module):
+    _enc = ()
+    _bott = ()
+    _dec = ()
+
+    def __init__(self, in_channels=3, out_channels=3, activation=nn.Identity()):
+        super().__init__()
+        self.input = nn.Conv2d(in_channels, 32, kernel_size=1, padding=0)
+        for k, (ci, co) in enumerate(self._enc, 1):
+            setattr(self, f"enc{k}", ConvBlockDownsample(ci, co))
+        self.bottleneck = ConvBlock(*self._bott)
+        for k, (ci, co) in enumerate(self._dec, 1):
+            setattr(self, f"dec{k}", ConvBlockUpsampleSkip(ci, co))
+        self.out = nn.Conv2d(32, out_channels, kernel_size=1, padding=0)
+        self.activation = activation
+
+    def _trunk(self, x, fuse=None):
+        div = 2 ** len(self._enc)
+        if x.dim() != 4 or x.shape[2] % div or x.shape[3] % div:
+            raise ValueError(f"input must be (B,C,H,W) with H, W divisible by {div}; got {tuple(x.shape)}")
+        h = _stem(self.input, x)
+        skips = [h]
+        for k in range(1, len(self._enc) + 1):
+            h = getattr(self, f"enc{k}")(h)
+            skips.append(h)
+        h = self.bottleneck(h) if fuse is None else fuse(h, skips)
+        for k in range(1, len(self._dec) + 1):
+            h = getattr(self, f"dec{k}")(h, skips[-k])
+        return _head(self.out, h)
+
+    @torch.compiler.disable
+    def forward(self, x):
+        return self.activation(self._trunk(x))
+
+
+class UNet(_UNetBase):
+    """3-level U-Net 32-64-128-256, bottleneck 512 (reference: models/UNet.py:7-76).  Note the
+    reference's geometry: bottleneck and enc3 are both at H/8, so dec1 up-samples to H/4 and
+    bilinearly resizes back to H/8."""
+    _enc = ((32, 64), (64, 128), (128, 256))
+    _bott = (256, 512)
+    _dec = ((512, 256), (256, 128), (128, 64), (64, 32))
+
+
+class LargeUNet(_UNetBase):
+    """4-level variant, bottleneck 1024 (reference: models/UNet.py:78-148)."""
+    _enc = ((32, 64), (64, 128), (128, 256), (256, 512))
+    _bott = (512, 1024)
+    _dec = ((1024, 512), (512, 256), (256, 128), (128, 64), (64, 32))

@@ -1,0 +1,203 @@
+/*
+ * hipseg.h -- C ABI of the MI355X-native (gfx950) U-Net / ClipUnet training hot path.
+ *
+ * The reference (MattiDeBeer/image-segmentation) has no FFI: its hot path is the
+ * implicit ATen op set behind models/processing_blocks.py, models/UNet.py,
+ * models/CLIP_models.py and models/losses.py.  Each entry point
+ * below replaces one of those implicit ops (cited as file:line under /root/reference)
+ * and is what a Python/ctypes, cgo or JNI binding for this path would bind.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *     (HBM) unless named *_host.  `stream` is a hipStream_t passed as void*.
+ *   - activations are dense NHWC ("channels-last"): elem(n,y,x,c) = base[((n*H+y)*W+x)*C+c].
+ *   - dtype: HIPSEG_F32 (float) or HIPSEG_BF16 (bfloat16 storage, fp32 accumulate).
+ *     Parameters, BN statistics, gradients of parameters and all reductions are fp32.
+ *   - every function only enqueues work on `stream` (no allocation, no sync: safe
+ *     under hipGraph capture) and returns 0 on success or a negative HIPSEG_E* code;
+ *     hipseg_last_error() gives the message for the calling thread.
+ */
+#ifndef HIPSEG_H
+#define HIPSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPSEG_F32 0
+#define HIPSEG_BF16 1
+
+#define HIPSEG_OK 0
+#define HIPSEG_EINVAL (-1) /* bad argument (shape/dtype/null) */
+#define HIPSEG_EHIP (-2)   /* HIP runtime error at launch */
+
+/* implicit-GEMM "conv" modes (hipseg_conv_igemm) */
+#define HIPSEG_CONV3 0   /* 3x3, pad 1, stride 1                                  */
+#define HIPSEG_CONV1 1   /* 1x1                                                   */
+#define HIPSEG_CONV2S2 2 /* 2x2, stride 2 (the data-gradient of ConvTranspose2d)   */
+#define HIPSEG_CONVT 3   /* ConvTranspose2d k2 s2 forward: 1x1 GEMM + pixel shuffle */
+
+typedef void* hipseg_stream_t;
+
+const char* hipseg_last_error(void);
+int hipseg_abi_version(void);
+
+/* ---- packed-weight geometry (pure host functions) -------------------------------- */
+/* K (reduction channels) is padded to the kernel's K-chunk, N (GEMM columns) to the
+ * kernel's column tile.  Packed layout: [tap][Kp/G][Np][G], G = 8 (bf16) or 1 (f32).  */
+int hipseg_kpad(int K, int dtype);
+int hipseg_npad(int N);
+/* number of M tiles (= rows of the per-tile statistics workspace) for a (B,H,W) pixel grid */
+int hipseg_conv_mtiles(int B, int H, int W);
+
+/* Conv2d weight (Cout,Cin,kh,kw) fp32 -> packed [tap][Kp/G][Np][G] in `dtype`.
+ * transpose=0: forward operand      (K = Cin, N = Cout, tap = ky*kw+kx)
+ * transpose=1: data-gradient operand (K = Cout, N = Cin, tap flipped: 3x3 conv dgrad is a
+ *              3x3 conv of dY with W[co][ci][2-ky][2-kx]).
+ * replaces: the implicit weight layout transforms inside cuDNN for nn.Conv2d
+ * (models/processing_blocks.py:43,46). */
+int hipseg_pack_conv_weight(const float* w, void* wp, int dtype, int Cout, int Cin, int ksize,
+                            int transpose, hipseg_stream_t stream);
+/* ConvTranspose2d weight (Cin,Cout,2,2) fp32.
+ * transpose=0: forward operand  (HIPSEG_CONVT: 1 tap, K = Cin, N = 4*Cout, n = (a*2+b)*Cout+co)
+ * transpose=1: data-gradient operand (HIPSEG_CONV2S2: 4 taps (a,b), K = Cout, N = Cin).
+ * (models/processing_blocks.py:102,128) */
+int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int Cin, int Cout, int transpose,
+                             hipseg_stream_t stream);
+
+/* ---- implicit-GEMM convolution (MFMA) ---------------------------------------------
+ * out[n,y,x,:] = bias + sum_taps sum_c in[n, tap(y,x), c] * W[tap][c][:]
+ *   in0/in1 : up to two NHWC sources concatenated along channels (C0 + C1 = K); in1 may be
+ *             NULL with C1 = 0.  This is torch.cat([x, skip], 1) eliminated
+ *             (models/processing_blocks.py:108).
+ *   out0/out1: output channel range split over two NHWC tensors (N0 + N1 = N); out1 may be
+ *             NULL.  Used by the data-gradient of a dual-source conv.
+ *   (H, W)  : the GEMM-M pixel grid = output grid for CONV3/CONV1/CONV2S2 (input grid is
+ *             2H x 2W for CONV2S2), INPUT grid for CONVT (output is 2H x 2W, N0 = Cout).
+ *   stats   : NULL or float[mtiles][2][N]: per-M-tile column sums and sums of squares of
+ *             the fp32 results (the BatchNorm batch-statistics partials, fused epilogue).
+ * replaces: aten::conv2d 3x3/1x1 (processing_blocks.py:43,46), its dgrad, and
+ *           aten::conv_transpose2d fwd/dgrad (processing_blocks.py:102,106). */
+int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
+                      const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
+                      float* stats, int B, int H, int W, hipseg_stream_t stream);
+
+/* ---- weight gradient (MFMA, split over pixel chunks) --------------------------------
+ * G[tap][u][v] = sum_pixels P[n, tap(y,x), u] * Q[n, y, x, v]
+ *   mode HIPSEG_CONV3 : P = layer input (p0|p1 dual source, CU = Cin), Q = dY (CV = Cout),
+ *                       result written as Conv2d weight grad (Cout,Cin,3,3).
+ *   mode HIPSEG_CONVT : P = dY of the transposed conv (2H x 2W, CU = Cout), Q = its input
+ *                       (H x W, CV = Cin); result written as (Cin,Cout,2,2).
+ *   mode HIPSEG_CONV1 : 1x1 conv weight grad (Cout,Cin,1,1), P = input, Q = dY.
+ *   (H, W) is Q's pixel grid.  `slabs` is a float workspace of
+ *   hipseg_wgrad_workspace_elems(...) elements; dw (fp32, the parameter's native layout) is
+ *   OVERWRITTEN with the reduced result.
+ * replaces: cuDNN conv backward-filter (autograd of processing_blocks.py:43,46,102). */
+size_t hipseg_wgrad_workspace_elems(int mode, int CU, int CV, int B, int H, int W);
+int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* p1, int CU1,
+                      const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
+                      hipseg_stream_t stream);
+
+/* ---- BatchNorm2d (train: batch statistics; eval: running statistics) ---------------
+ * bn_finalize: reduce the conv epilogue partials -> mean, invstd, scale = gamma*invstd,
+ *   shift = beta - mean*scale; running_mean/var updated with momentum (unbiased var) and
+ *   num_batches_tracked += 1 when the pointers are non-NULL.  count = B*H*W.
+ * bn_eval_params: scale/shift/mean/invstd from running statistics.
+ * (nn.BatchNorm2d, models/processing_blocks.py:44,47; eps 1e-5, momentum 0.1) */
+int hipseg_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float* mean,
+                       float* invstd, float* scale, float* shift, hipseg_stream_t stream);
+int hipseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int C, float* mean, float* invstd,
+                          float* scale, float* shift, hipseg_stream_t stream);
+/* y = relu(x*scale + shift); pool != 0 additionally applies MaxPool2d(2,2) and writes the
+ * pooled (H/2 x W/2) tensor only.  (processing_blocks.py:44-45,47-48,73) */
+int hipseg_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y,
+                         int B, int H, int W, int C, int pool, hipseg_stream_t stream);
+/* Backward of y = [maxpool](relu(bn(x))).  dy is at the pooled resolution when pool != 0.
+ * Step 1 (reduce): partial[blk][2][C] <- sum g, sum g*xhat   (g = dy routed through pool/relu)
+ * Step 2 (finalize, hipseg_colsum_finalize with rows = 2): sums[2][C] = dbeta, dgamma
+ * Step 3 (apply): dx = scale*(g - dbeta/count - xhat*dgamma/count)   (train)
+ *                 dx = scale*g                                        (eval != 0)
+ *         and, when dbias != NULL, dbias[c] += sum_pixels dx (atomic; conv bias gradient). */
+int hipseg_bn_bwd_blocks(int B, int H, int W, int C, int dtype, int pool);
+int hipseg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* mean,
+                         const float* invstd, const float* scale, const float* shift,
+                         float* partial, int B, int H, int W, int C, int pool,
+                         hipseg_stream_t stream);
+int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* mean,
+                        const float* invstd, const float* scale, const float* shift,
+                        const float* sums, double count, int eval, void* dx, float* dbias, int B,
+                        int H, int W, int C, int pool, hipseg_stream_t stream);
+
+/* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic). */
+int hipseg_colsum_finalize(const float* partial, int nblk, int rows, int C, float* out,
+                           hipseg_stream_t stream);
+/* per-channel sum over pixels of an NHWC tensor: out[c] = sum_p x[p][c] (bias gradients). */
+int hipseg_colsum_blocks(long npix, int C, int dtype);
+int hipseg_colsum(int dtype, const void* x, long npix, int C, float* partial, float* out,
+                  hipseg_stream_t stream);
+
+/* ---- 1x1 stem / head ----------------------------------------------------------------
+ * stem: Conv2d(Cin, Cout, 1) on an NCHW fp32 image -> NHWC activations (models/UNet.py:39,62).
+ * stem_bwd: dW (Cout,Cin), db (Cout) from dY (NHWC) and the NCHW image (no data gradient:
+ *           the image does not require grad).  dw/db are overwritten. */
+int hipseg_stem_fwd(int dtype, const float* x_nchw, const float* w, const float* b, void* y, int B,
+                    int Cin, int H, int W, int Cout, hipseg_stream_t stream);
+int hipseg_stem_bwd_blocks(int B, int H, int W);
+int hipseg_stem_bwd(int dtype, const float* x_nchw, const void* dy, float* partial, float* dw,
+                    float* db, int B, int Cin, int H, int W, int Cout, hipseg_stream_t stream);
+/* head: Conv2d(Cin, Cout<=8, 1) NHWC activations -> NCHW fp32 logits (models/UNet.py:55,73).
+ * head_bwd: dX (NHWC, dtype), dW (Cout,Cin), db (Cout) from NCHW fp32 dlogits. */
+int hipseg_head_fwd(int dtype, const void* x, const float* w, const float* b, float* logits_nchw,
+                    int B, int H, int W, int Cin, int Cout, hipseg_stream_t stream);
+int hipseg_head_bwd_blocks(int B, int H, int W);
+int hipseg_head_bwd(int dtype, const void* x, const float* dlogits_nchw, const float* w, void* dx,
+                    float* partial, float* dw, float* db, int B, int H, int W, int Cin, int Cout,
+                    hipseg_stream_t stream);
+
+/* ---- bilinear resize, align_corners=True (processing_blocks.py:107), NHWC ---------- */
+int hipseg_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo,
+                        int C, hipseg_stream_t stream);
+int hipseg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo,
+                        int C, hipseg_stream_t stream);
+
+/* ---- losses (models/losses.py) ----------------------------------------------------------
+ * ce: nn.CrossEntropyLoss() on NCHW fp32 logits (B,C,H,W), int64 targets (B,H,W)
+ *     (HybridLoss.forward, losses.py:13-15).  loss[0] = mean NLL over the non-ignored
+ *     (target != -100) pixels, loss[1] = their count.
+ * ce_bwd: dlogits = (softmax - onehot) * gscale[0] / loss[1]; gscale is a DEVICE scalar
+ *     (the upstream gradient, e.g. GradScaler's scale) so no host sync is needed; `loss`
+ *     is the 2-float buffer ce_fwd wrote. */
+int hipseg_loss_blocks(long n);
+int hipseg_ce_fwd(const float* logits, const int64_t* target, float* partial, float* loss, int B,
+                  int C, long HW, hipseg_stream_t stream);
+int hipseg_ce_bwd(const float* logits, const int64_t* target, const float* gscale, const float* loss,
+                  float* dlogits, int B, int C, long HW, hipseg_stream_t stream);
+/* bce_dice: HybridLossBinary.forward (losses.py:24-36): BCEWithLogits(mean) + smp DiceLoss
+ *     (mode binary, from_logits=True applied to sigmoid(pred), smooth 0, eps 1e-7).
+ *     sums[4] = {sum bce, sum p*t, sum p, sum t} with p = sigmoid(sigmoid(x)); loss[0] = total. */
+int hipseg_bce_dice_fwd(const float* logits, const float* target, float* partial, float* sums,
+                        float* loss, long n, hipseg_stream_t stream);
+int hipseg_bce_dice_bwd(const float* logits, const float* target, const float* sums,
+                        const float* gscale, float* dlogits, long n, hipseg_stream_t stream);
+/* segmentation metrics (IoU / PixelAccuracy, losses.py:38-63,129-154): CxC confusion
+ * matrix of argmax(logits) vs target, conf[t*C + p] (int64 counts; conf is overwritten). */
+int hipseg_confusion(const float* logits, const int64_t* target, long long* conf, int B, int C,
+                     long HW, hipseg_stream_t stream);
+
+/* ---- layout helpers ---------------------------------------------------------------------- */
+/* NCHW fp32 <-> NHWC dtype (for standalone block use with contiguous NCHW callers). */
+int hipseg_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W,
+                        hipseg_stream_t stream);
+int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W,
+                        hipseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPSEG_H */

@@ -94,7 +94,7 @@ def gen_blocks():
 
 
 # ------------------------------------------------------------------ whole-model fixtures
-def _model_case(out, tag, model, x, target, adam_steps=0, grad_keys=()):
+def _model_case(out, tag, model, x, target, adam_steps=0, grad_keys=(), bf16_yardstick=False):
     fill.fill_state_dict(model.state_dict())
     model.eval()
     with torch.no_grad():
@@ -105,6 +105,16 @@ def _model_case(out, tag, model, x, target, adam_steps=0, grad_keys=()):
     loss.backward()
     out[f"{tag}/train_logits"] = npy(logits)
     out[f"{tag}/ce_loss"] = npy(loss)
+    if bf16_yardstick:
+        # the reference's OWN reduced-precision path (torch.autocast bf16 on CPU), as a yardstick for
+        # what "bf16" costs on these weights; buffers are restored so the fixtures above stay valid
+        saved = {k: v.clone() for k, v in model.state_dict().items()}
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            model.eval()
+            out[f"{tag}/bf16ref_eval_logits"] = npy(model(x).float())
+            model.train()
+            out[f"{tag}/bf16ref_train_logits"] = npy(model(x).float())
+        model.load_state_dict(saved)
     for k, p in model.named_parameters():
         g = p.grad
         out[f"{tag}/gradstat/{k}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()),
@@ -133,7 +143,7 @@ def gen_models():
     out = {}
     x = T("c1.x", (2, 3, 128, 128))
     t = torch.from_numpy(fill.randint("c1.t", (2, 128, 128), 3))
-    _model_case(out, "unet_c1", UNet(), x, t, adam_steps=5,
+    _model_case(out, "unet_c1", UNet(), x, t, adam_steps=5, bf16_yardstick=True,
                 grad_keys=("input.weight", "input.bias", "enc1.block.0.conv.0.weight",
                            "enc1.block.0.conv.1.weight", "enc1.block.0.conv.1.bias",
                            "bottleneck.conv.3.bias", "dec1.up.bias", "dec4.up.weight",

@@ -1,0 +1,311 @@
+"""Kernel-level parity: each C-ABI entry point vs the CPU oracle (plain PyTorch fp32 on the same
+inputs).  Needs a real MI355X.  Tolerances: fp32 kernels 1e-4-class (stated per test); bf16 kernels
+are compared against the oracle evaluated on the bf16-rounded operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fill  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hs():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import hipseg  # noqa: F401
+    from hipseg import _lib as L, ops
+
+    class H:
+        pass
+
+    h = H()
+    h.L, h.ops = L, ops
+    return h
+
+
+DTYPES = [("fp32", torch.float32, 0), ("bf16", torch.bfloat16, 1)]
+
+
+def T(name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(fill.uniform(name, shape, lo, hi))
+
+
+def rnd(t, td):
+    """round a CPU fp32 tensor through the storage dtype"""
+    return t.detach().to(td).float().clone()
+
+
+def to_dev_nhwc(t, td):
+    return t.cuda().to(td).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def tol(td, scale=1.0):
+    return (2e-5 * scale + 1e-5, 1e-4) if td == torch.float32 else (1.5e-2 * scale, 1.5e-2)
+
+
+def check(got, want, td, scale=None, what=""):
+    got = got.float().cpu()
+    scale = float(want.abs().max()) if scale is None else scale
+    atol, rtol = tol(td, max(scale, 1e-6))
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} (scale {scale:.3e})"
+
+
+CONV_CASES = [
+    # B, C0, C1, Cout, H, W
+    (2, 4, 0, 8, 16, 16),
+    (1, 32, 0, 64, 16, 16),
+    (1, 8, 0, 8, 8, 24),
+    (2, 16, 0, 32, 20, 12),
+    (1, 64, 0, 128, 32, 32),
+    (1, 8, 8, 8, 16, 16),
+    (1, 32, 32, 32, 24, 40),
+    (1, 128, 0, 256, 8, 8),
+    (1, 24, 0, 40, 16, 16),
+    (1, 5, 0, 7, 10, 18),
+]
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3_fwd_stats(hs, prec, td, dt, case):
+    B, C0, C1, Cout, H, W = case
+    L, ops = hs.L, hs.ops
+    x0 = rnd(T("k.x0", (B, C0, H, W)), td)
+    x1 = rnd(T("k.x1", (B, C1, H, W)), td) if C1 else None
+    w = T("k.w", (Cout, C0 + C1, 3, 3), -0.3, 0.3)
+    b = T("k.b", (Cout,), -0.5, 0.5)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    want = F.conv2d(xin, rnd(w, td), b, padding=1)
+    dx0 = to_dev_nhwc(x0, td)
+    dx1 = to_dev_nhwc(x1, td) if C1 else None
+    wp = ops._pack_conv(w.cuda(), dt, False)
+    out = ops.nhwc_empty(B, Cout, H, W, td, "cuda")
+    mt = L.conv_mtiles(B, H, W)
+    stats = torch.full((mt, 2, Cout), float("nan"), device="cuda")
+    s = ops._stream()
+    bd = b.cuda()  # keep alive: raw pointers are passed
+    L.conv_igemm(dt, L.CONV3, ops.ptr(dx0), C0, ops.ptr(dx1), C1, ops.ptr(wp), ops.ptr(bd), ops.ptr(out), Cout, 0, 0,
+                 ops.ptr(stats), B, H, W, s)
+    torch.cuda.synchronize()
+    check(out, want, td, what="conv3 fwd")
+    st = stats.cpu().double().sum(0)
+    ssum = want.double().sum((0, 2, 3))
+    ssq = (want.double() ** 2).sum((0, 2, 3))
+    n = B * H * W
+    rt = 1e-4 if td == torch.float32 else 2e-2
+    np.testing.assert_allclose(st[0].numpy(), ssum.numpy(), rtol=rt, atol=rt * n * 0.05)
+    np.testing.assert_allclose(st[1].numpy(), ssq.numpy(), rtol=rt, atol=rt * n * 0.05)
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3_dgrad_wgrad(hs, prec, td, dt, case):
+    B, C0, C1, Cout, H, W = case
+    L, ops = hs.L, hs.ops
+    Cin = C0 + C1
+    x = rnd(T("g.x", (B, Cin, H, W)), td).requires_grad_(True)
+    w = T("g.w", (Cout, Cin, 3, 3), -0.3, 0.3)
+    wr = rnd(w, td).requires_grad_(True)
+    dy = rnd(T("g.dy", (B, Cout, H, W)), td)
+    F.conv2d(x, wr, None, padding=1).backward(dy)
+    s = ops._stream()
+    ddy = to_dev_nhwc(dy, td)
+    # dgrad with split destination
+    wpt = ops._pack_conv(w.cuda(), dt, True)
+    dx0 = ops.nhwc_empty(B, C0, H, W, td, "cuda")
+    dx1 = ops.nhwc_empty(B, C1, H, W, td, "cuda") if C1 else None
+    L.conv_igemm(dt, L.CONV3, ops.ptr(ddy), Cout, 0, 0, ops.ptr(wpt), 0, ops.ptr(dx0), C0, ops.ptr(dx1), C1, 0, B, H, W, s)
+    torch.cuda.synchronize()
+    check(dx0, x.grad[:, :C0], td, scale=float(x.grad.abs().max()), what="dgrad out0")
+    if C1:
+        check(dx1, x.grad[:, C0:], td, scale=float(x.grad.abs().max()), what="dgrad out1")
+    # wgrad with dual source
+    xd = x.detach()
+    p0 = to_dev_nhwc(xd[:, :C0], td)
+    p1 = to_dev_nhwc(xd[:, C0:], td) if C1 else None
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    ops._wgrad(dt, L.CONV3, p0, p1, ddy, dw, B, H, W)
+    torch.cuda.synchronize()
+    # operands are exactly representable in the storage dtype, products accumulate in fp32
+    g = wr.grad
+    err = (dw.cpu() - g).abs().max()
+    assert err <= 2e-4 * max(1.0, float(g.abs().max())), f"wgrad max err {float(err):.3e} vs scale {float(g.abs().max()):.3e}"
+
+
+CONVT_CASES = [(2, 16, 8, 8, 8), (1, 64, 32, 4, 12), (1, 128, 64, 16, 16), (1, 12, 6, 5, 7)]
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[str(c) for c in CONVT_CASES])
+def test_convT(hs, prec, td, dt, case):
+    B, Cin, Cout, H, W = case
+    ops = hs.ops
+    x = rnd(T("t.x", (B, Cin, H, W)), td).requires_grad_(True)
+    w = T("t.w", (Cin, Cout, 2, 2), -0.3, 0.3)
+    wr = rnd(w, td).requires_grad_(True)
+    b = T("t.b", (Cout,), -0.5, 0.5).requires_grad_(True)
+    dy = rnd(T("t.dy", (B, Cout, 2 * H, 2 * W)), td)
+    y = F.conv_transpose2d(x, wr, b, stride=2)
+    y.backward(dy)
+    dx_ = to_dev_nhwc(x.detach(), td).requires_grad_(True)
+    dw_ = w.cuda().requires_grad_(True)
+    db_ = b.detach().cuda().requires_grad_(True)
+    yy = ops.ConvT2x2Fn.apply(dx_, dw_, db_)
+    yy.backward(to_dev_nhwc(dy, td))
+    torch.cuda.synchronize()
+    check(yy.detach(), y.detach(), td, what="convT fwd")
+    check(dx_.grad, x.grad, td, what="convT dgrad")
+    assert (dw_.grad.cpu() - wr.grad).abs().max() <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
+    rt = 1e-4 if td == torch.float32 else 1e-2
+    np.testing.assert_allclose(db_.grad.cpu().numpy(), b.grad.numpy(), rtol=rt, atol=rt * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 64, 8, 24), (2, 6, 4, 6), (1, 256, 8, 8)])
+def test_bn_relu_pool_fwd_bwd(hs, prec, td, dt, pool, shape):
+    B, C, H, W = shape
+    L, ops = hs.L, hs.ops
+    x = rnd(T("bn.x", shape, -2, 2), td).requires_grad_(True)
+    gamma = T("bn.g", (C,), 0.5, 1.5).requires_grad_(True)
+    beta = T("bn.b", (C,), -0.3, 0.3).requires_grad_(True)
+    y = F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5))
+    if pool:
+        y = F.max_pool2d(y, 2, 2)
+    dy = rnd(T("bn.dy", tuple(y.shape)), td)
+    y.backward(dy)
+    # device: statistics from exact double sums (the conv epilogue is tested separately)
+    xd = x.detach().double()
+    stats = torch.stack([xd.sum((0, 2, 3)), (xd ** 2).sum((0, 2, 3))]).float().reshape(1, 2, C).cuda()
+    bn = ops._BN(C, "cuda")
+    s = ops._stream()
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()  # keep alive: raw pointers are passed
+    L.bn_finalize(ops.ptr(stats), 1, C, float(B * H * W), ops.ptr(gd), ops.ptr(bd),
+                  1e-5, 0.1, ops.ptr(rm), ops.ptr(rv), ops.ptr(nbt), ops.ptr(bn.mean), ops.ptr(bn.invstd),
+                  ops.ptr(bn.scale), ops.ptr(bn.shift), s)
+    raw = to_dev_nhwc(x.detach(), td)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    act = ops.nhwc_empty(B, C, Ho, Wo, td, "cuda")
+    L.bn_relu_apply(dt, ops.ptr(raw), ops.ptr(bn.scale), ops.ptr(bn.shift), ops.ptr(act), B, H, W, C, int(pool), s)
+    torch.cuda.synchronize()
+    check(act, y.detach(), td, what="bn+relu(+pool) fwd")
+    assert int(nbt) == 1
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * xd.mean((0, 2, 3)).float().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * xd.var((0, 2, 3), unbiased=True)).float().numpy(), rtol=1e-4)
+    draw, dg, dbe, dbias = ops._bn_relu_bwd(dt, to_dev_nhwc(dy, td), raw, bn, True, pool)
+    torch.cuda.synchronize()
+    check(draw, x.grad, td, scale=float(x.grad.abs().max()), what="bn bwd dx")
+    rt = 2e-4 if td == torch.float32 else 2e-2
+    np.testing.assert_allclose(dg.cpu().numpy(), gamma.grad.numpy(), rtol=rt, atol=rt * float(gamma.grad.abs().max()))
+    np.testing.assert_allclose(dbe.cpu().numpy(), beta.grad.numpy(), rtol=rt, atol=rt * float(beta.grad.abs().max()))
+    # conv-bias gradient = sum of the (un-rounded fp32) dx; in train mode the exact value is 0
+    want_db = x.grad.double().sum((0, 2, 3)).numpy()
+    mag = x.grad.double().abs().sum((0, 2, 3)).numpy()
+    assert np.all(np.abs(dbias.cpu().numpy() - want_db) <= 1e-5 * mag + 1e-6)
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+def test_stem_head(hs, prec, td, dt):
+    ops = hs.ops
+    B, H, W = 2, 16, 24
+    x = T("s.x", (B, 3, H, W), 0, 1)
+    w = T("s.w", (32, 3, 1, 1)).requires_grad_(True)
+    b = T("s.b", (32,), -0.1, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    dy = rnd(T("s.dy", (B, 32, H, W)), td)
+    y.backward(dy)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yy = ops.StemFn.apply(x.cuda(), wd, bd, prec)
+    yy.backward(to_dev_nhwc(dy, td))
+    torch.cuda.synchronize()
+    check(yy.detach(), y.detach(), td, what="stem fwd")
+    assert (wd.grad.cpu() - w.grad).abs().max() <= 2e-4 * float(w.grad.abs().max())
+    assert (bd.grad.cpu() - b.grad).abs().max() <= 2e-4 * float(b.grad.abs().max())
+    # head
+    for cout in (3, 1):
+        hx = rnd(T("h.x", (B, 32, H, W)), td).requires_grad_(True)
+        hw = T("h.w", (cout, 32, 1, 1)).requires_grad_(True)
+        hb = T("h.b", (cout,), -0.1, 0.1).requires_grad_(True)
+        lg = F.conv2d(hx, hw, hb)
+        dl = T("h.dl", (B, cout, H, W))
+        lg.backward(dl)
+        dxh = to_dev_nhwc(hx.detach(), td).requires_grad_(True)
+        dwh, dbh = hw.detach().cuda().requires_grad_(True), hb.detach().cuda().requires_grad_(True)
+        lgd = ops.HeadFn.apply(dxh, dwh, dbh)
+        lgd.backward(dl.cuda())
+        torch.cuda.synchronize()
+        assert lgd.dtype == torch.float32 and lgd.is_contiguous()
+        assert (lgd.detach().cpu() - lg.detach()).abs().max() <= 1e-4
+        check(dxh.grad, hx.grad, td, what="head dx")
+        assert (dwh.grad.cpu() - hw.grad).abs().max() <= 2e-4 * float(hw.grad.abs().max())
+        assert (dbh.grad.cpu() - hb.grad).abs().max() <= 2e-4 * float(hb.grad.abs().max())
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("geo", [(16, 16, 8, 8), (8, 24, 4, 12), (8, 8, 16, 16), (6, 10, 6, 10), (4, 4, 1, 1)])
+def test_bilinear(hs, prec, td, dt, geo):
+    ops = hs.ops
+    Hi, Wi, Ho, Wo = geo
+    x = rnd(T("bl.x", (2, 8, Hi, Wi)), td).requires_grad_(True)
+    y = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = rnd(T("bl.dy", (2, 8, Ho, Wo)), td)
+    y.backward(dy)
+    xd = to_dev_nhwc(x.detach(), td).requires_grad_(True)
+    yd = ops.BilinearFn.apply(xd, Ho, Wo)
+    yd.backward(to_dev_nhwc(dy, td))
+    torch.cuda.synchronize()
+    check(yd.detach(), y.detach(), td, what="bilinear fwd")
+    check(xd.grad, x.grad, td, what="bilinear bwd")
+
+
+def test_losses_and_confusion(hs, golden):
+    ops = hs.ops
+    g = golden("losses")
+    logits = T("loss.logits", (2, 3, 32, 32), -3.0, 3.0)
+    tgt = torch.from_numpy(fill.randint("loss.t", (2, 32, 32), 3))
+    lg = logits.cuda().requires_grad_(True)
+    ce = ops.CrossEntropyFn.apply(lg, tgt.cuda())
+    (ce * 3.0).backward()
+    assert abs(float(ce) - float(g["ce"])) < 2e-6
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), 3.0 * g["ce_grad"], rtol=1e-4, atol=1e-9)
+    # ignore_index = -100
+    t2 = tgt.clone()
+    t2[0, :5] = -100
+    l2 = logits.clone().requires_grad_(True)
+    want = F.cross_entropy(l2, t2)
+    want.backward()
+    l2d = logits.cuda().requires_grad_(True)
+    got = ops.CrossEntropyFn.apply(l2d, t2.cuda())
+    got.backward()
+    assert abs(float(got) - float(want)) < 2e-6
+    np.testing.assert_allclose(l2d.grad.cpu().numpy(), l2.grad.numpy(), rtol=1e-4, atol=1e-9)
+    conf = ops.confusion_matrix(logits.cuda(), tgt.cuda()).cpu()
+    pred = logits.argmax(1)
+    for t in range(3):
+        for p in range(3):
+            assert int(conf[t, p]) == int(((tgt == t) & (pred == p)).sum())
+    # BCE + Dice
+    from oracle import torch_ref as R
+    bl = T("loss.blogits", (2, 1, 32, 32), -3.0, 3.0)
+    bt = torch.from_numpy(fill.randint("loss.bt", (2, 32, 32), 2)).float().unsqueeze(1)
+    blr = bl.clone().requires_grad_(True)
+    want = R.hybrid_loss_binary(blr, bt)
+    want.backward()
+    bld = bl.cuda().requires_grad_(True)
+    got = ops.BceDiceFn.apply(bld, bt.cuda())
+    got.backward()
+    assert abs(float(got) - float(want)) < 5e-6
+    np.testing.assert_allclose(bld.grad.cpu().numpy(), blr.grad.numpy(), rtol=2e-4, atol=1e-8)
+    # empty target: dice masked, BCE only
+    z = torch.zeros_like(bt)
+    want0 = R.hybrid_loss_binary(bl, z)
+    got0 = ops.BceDiceFn.apply(bl.cuda(), z.cuda())
+    assert abs(float(got0) - float(want0)) < 5e-6
