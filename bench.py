@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one full U-Net train step on synthetic 3x256x256 batches
+(BASELINE.json configs[1]: UNet, batch 16 per GPU, bf16) -- forward + cross-entropy + backward
+(+ bucketed RCCL gradient all-reduce for N > 1) + GradScaler/Adam step, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel (most device time) of the step -- achieved algorithmic
+                 TFLOP/s from HIP-event timing of every launch of that kernel, vs the dense bf16
+                 MFMA peak;
+  cpu_baseline : the CPU oracle (oracle/torch_ref.py, fp32 PyTorch restatement of the reference)
+                 timed on this box's host cores on a bounded sample of the same workload
+                 (rank 0, N = 1 only);
+  kernels      : per-kernel breakdown from the same event timing (informational).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "image-segmentation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG = 136.17  # 3 x 45.39 GFLOP fwd, UNet @ 3x256x256
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet"])
+    ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "graph"), choices=["eager", "graph"],
+                    help="eager: Python launches every kernel each step; graph: the whole step is one hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle's train step (fwd + CE + bwd + Adam, fp32) on the host cores, bounded sample."""
+    import torch
+    from oracle.torch_ref import OracleTrainer
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tr = OracleTrainer(args.model)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(args.cpu_batch, 3, args.size, args.size, generator=g)
+    t = torch.randint(0, 3, (args.cpu_batch, args.size, args.size), generator=g)
+    tr.step(x, t)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        tr.step(x, t)
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return {"value": round(args.cpu_batch / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} steps of batch {args.cpu_batch} x 3x{args.size}x{args.size} fp32 "
+                      f"(oracle/torch_ref.OracleTrainer, torch {torch.__version__} CPU, {cores} threads), 1 warm-up"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world)
+
+    import hipseg
+    from hipseg import ops
+    from hipseg.ddp import HipDDP
+    import models.UNet as un
+    from models.losses import HybridLoss
+
+    torch.manual_seed(0)
+    model = getattr(un, args.model)().to(dev).train()
+    net = HipDDP(model) if world > 1 else model
+    crit = HybridLoss()
+    use_graph = args.loop == "graph" and world == 1
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=use_graph)
+    scaler = torch.amp.GradScaler("cuda")
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
+    t = torch.randint(0, 3, (args.batch, args.size, args.size), generator=g).to(dev)
+
+    def step():
+        # loop body of the reference's TrainingWrapper.train (models/model_wrappers.py:167-177)
+        opt.zero_grad(set_to_none=not use_graph)
+        with torch.autocast("cuda"):
+            out = net(x)
+            loss = crit(out, t)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                loss = step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=False)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def run():
+            graph.replay()
+            return static_loss
+    else:
+        run = step
+
+    for _ in range(args.warmup):
+        loss = run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    final_loss = float(loss)
+    ms = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+
+    out = {
+        "metric": "images/sec (whole node) U-Net 3x256x256 train step",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} 3x{args.size}x{args.size} train step (fwd + CE + bwd + GradScaler/Adam"
+                               f"{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch {args.batch}/GPU, "
+                               f"BASELINE.json configs[1]",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "loop": "hipgraph" if use_graph else "eager",
+                   "weights": "random init (nn default)", "final_loss": round(final_loss, 5)},
+        "step_fraction_of_mfma_bound": round((TRAIN_GFLOP_PER_IMG * args.batch / 1e3 / PEAK_BF16_TFLOPS) / (ms / 1e3), 4)
+        if args.model == "UNet" and args.size == 256 else None,
+    }
+
+    # ---- roofline leg: event-time every MFMA kernel launch over a few eager steps on this stream
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = []
+        nprof = 3
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in ops.PROFILE:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1)  # ms
+        ops.PROFILE = None
+        kern = {k: {"launches_per_step": v[0] // nprof, "avg_ms": round(v[2] / v[0], 5),
+                    "ms_per_step": round(v[2] / nprof, 4), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2)}
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+        dom = max(agg.items(), key=lambda kv: kv[1][2])
+        ach = dom[1][1] / (dom[1][2] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": dom[1][0] // nprof, "avg_launch_ms": round(dom[1][2] / dom[1][0], 5),
+                           "flops_per_launch_avg": dom[1][1] / dom[1][0]}
+        out["kernels"] = kern
+        out["mfma_kernels_ms_per_step"] = round(sum(v[2] for v in agg.values()) / nprof, 4)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""Data-parallel gradient reducer: bucketed all-reduce over RCCL/xGMI on a side HIP stream,
+overlapped with backward.  Replaces torch DDP as used by the reference
+(scripts/train_distributed.py:35 `DDP(model, device_ids=[rank])`, models/model_wrappers.py:974-978).
+
+Semantics kept from DDP: parameters (and buffers) broadcast from rank 0 at construction; gradients
+averaged over ranks every backward; BatchNorm statistics stay per-replica (no SyncBN) with the
+buffers re-broadcast from rank 0 at every training forward; `.module` exposes the wrapped model so
+`model.module.__class__.__name__` (model_wrappers.py:868) and `module.`-prefixed checkpoints work.
+
+Design for xGMI (point-to-point links, no switch): few, large messages.  Gradients are packed into
+flat fp32 buckets in REVERSE registration order (out/dec4 first, stem last -- the order backward
+produces them); each bucket is all-reduced as soon as its last gradient has been accumulated, on a
+dedicated stream that waits on an event recorded on the compute stream, so only the last (small:
+stem/enc1) bucket is exposed after backward.  One process per GPU; no data-path collective other
+than this all-reduce.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "views", "pending", "work")
+
+    def __init__(self, params, device):
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.params = params
+        self.views = []
+        o = 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class HipDDP(nn.Module):
+    def __init__(self, module, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0, broadcast_buffers=True):
+        super().__init__()
+        if not dist.is_initialized():
+            raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.broadcast_buffers = broadcast_buffers
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        self.device = params[0].device
+        self.on_gpu = self.device.type == "cuda"
+        # ---- buckets, reverse registration order; first bucket small so the reduction starts early
+        self.buckets, self._where = [], {}
+        cur, cur_bytes, cap = [], 0, first_bucket_mb * 2 ** 20
+        for p in reversed(params):
+            if p.dtype != torch.float32:
+                raise TypeError("HipDDP reduces fp32 master gradients")
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= cap:
+                self.buckets.append(_Bucket(cur, self.device))
+                cur, cur_bytes, cap = [], 0, bucket_cap_mb * 2 ** 20
+        if cur:
+            self.buckets.append(_Bucket(cur, self.device))
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._where[p] = (bi, pi)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self._cb_queued = False
+        self._require_sync = True
+        # ---- initial state broadcast (rank 0 wins), as DDP's constructor does
+        with torch.no_grad():
+            self._bcast([p.data for p in module.parameters()])
+            # floating-point buffers (BN running statistics) are re-pointed into ONE flat tensor so the
+            # per-forward DDP buffer broadcast is a single collective with no gather/scatter copies
+            fbufs = [b for b in module.buffers() if b.is_floating_point()]
+            self._flat_buffers = None
+            if fbufs:
+                flat = torch.cat([b.reshape(-1).float() for b in fbufs])
+                o = 0
+                for b in fbufs:
+                    b.data = flat[o:o + b.numel()].view_as(b)
+                    o += b.numel()
+                self._flat_buffers = flat
+                dist.broadcast(flat, 0, group=self.pg)
+            for b in module.buffers():
+                if not b.is_floating_point():
+                    dist.broadcast(b, 0, group=self.pg)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    # ------------------------------------------------------------------ helpers
+    def _bcast(self, tensors):
+        if not tensors:
+            return
+        flat = torch.cat([t.reshape(-1).float() for t in tensors])
+        dist.broadcast(flat, 0, group=self.pg)
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+
+    def no_sync(self):
+        """context manager: accumulate local gradients without reducing (gradient accumulation)."""
+        ddp = self
+
+        class _Ctx:
+            def __enter__(self_):
+                ddp._require_sync = False
+
+            def __exit__(self_, *a):
+                ddp._require_sync = True
+
+        return _Ctx()
+
+    # ------------------------------------------------------------------ backward side
+    def _hook(self, p):
+        if not self._require_sync or self.world == 1:
+            return
+        bi, pi = self._where[p]
+        b = self.buckets[bi]
+        view = b.views[pi]
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view  # gradient-as-bucket-view: the optimiser reads the reduced values in place
+        b.pending -= 1
+        if not self._cb_queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+            self._cb_queued = True
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:  # gloo (CPU tests): no AVG op, no streams
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _finalize(self):
+        """end of backward: join the communication stream, re-arm the buckets."""
+        for b in self.buckets:
+            if b.pending != 0 and b.pending != len(b.params):
+                # parameters unused in this backward: reduce what we have (their slots hold stale/zero data)
+                self._launch(b)
+            if b.work is not None:
+                if self.on_gpu:
+                    b.work.wait()  # makes the CURRENT stream wait for the collective (no host block)
+                else:
+                    b.work.wait()
+                    b.flat.div_(self.world)
+                b.work = None
+            b.pending = len(b.params)
+        self._cb_queued = False
+
+    # ------------------------------------------------------------------ forward side
+    def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.world > 1 and self.module.training and torch.is_grad_enabled():
+            if self._flat_buffers is not None:
+                dist.broadcast(self._flat_buffers, 0, group=self.pg)
+        return self.module(*args, **kwargs)

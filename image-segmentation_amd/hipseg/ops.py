@@ -83,6 +83,35 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+# ---------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every MFMA kernel
+# launch is bracketed by HIP events on the launch stream and recorded as
+# (kernel key, algorithmic FLOPs, event0, event1).  None (default) = zero overhead.
+PROFILE = None
+_TAPS = {L.CONV3: 9, L.CONV1: 1, L.CONV2S2: 4, L.CONVT: 1}
+_MODE_NAME = {L.CONV3: "CONV3", L.CONV1: "CONV1", L.CONV2S2: "CONV2S2", L.CONVT: "CONVT"}
+
+
+def _timed(key, flops, fn, *args):
+    if PROFILE is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn(*args)
+    e1.record()
+    PROFILE.append((key, flops, e0, e1))
+
+
+def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H, W):
+    """hipseg_conv_igemm on the current stream (tensors or None in, raw pointers out)."""
+    N = 4 * n0 if mode == L.CONVT else n0 + n1
+    bn = 128 if N > 64 else (64 if N > 32 else 32)
+    key = f"conv_igemm<{'bf16' if dt == L.BF16 else 'f32'},{_MODE_NAME[mode]},BN{bn}>"
+    flops = 2.0 * B * H * W * N * (c0 + c1) * _TAPS[mode]
+    _timed(key, flops, L.conv_igemm, dt, mode, ptr(in0), c0, ptr(in1), c1, ptr(wp), ptr(bias), ptr(out0), n0,
+           ptr(out1), n1, ptr(stats), B, H, W, _stream())
+
+
 def _pack_conv(w, dt, transpose):
     cout, cin, k, _ = w.shape
     K, N = (cout, cin) if transpose else (cin, cout)
@@ -108,7 +137,10 @@ def _wgrad(dt, mode, p0, p1, q, dw, B, H, W):
     cu1 = p1.shape[1] if p1 is not None else 0
     cv = q.shape[1]
     slabs = _f32(L.wgrad_workspace_elems(mode, cu0 + cu1, cv, B, H, W), dw.device)
-    L.conv_wgrad(dt, mode, ptr(p0), cu0, ptr(p1), cu1, ptr(q), cv, ptr(dw), ptr(slabs), B, H, W, _stream())
+    nt = 9 if mode == L.CONV3 else (4 if mode == L.CONVT else 1)
+    key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},{_MODE_NAME[mode]}>(+reduce)"
+    _timed(key, 2.0 * B * H * W * (cu0 + cu1) * cv * nt, L.conv_wgrad, dt, mode, ptr(p0), cu0, ptr(p1), cu1, ptr(q),
+           cv, ptr(dw), ptr(slabs), B, H, W, _stream())
 
 
 class _BN:
@@ -135,11 +167,11 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool):
     if train:
         mt = L.conv_mtiles(B, H, W)
         stats = _f32(mt * 2 * cout, dev)
-        L.conv_igemm(dt, L.CONV3, ptr(x0), c0, ptr(x1), c1, ptr(wp), ptr(b), ptr(raw), cout, 0, 0, ptr(stats), B, H, W, s)
+        igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, stats, B, H, W)
         L.bn_finalize(ptr(stats), mt, cout, float(B * H * W), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm), ptr(rv),
                       ptr(nbt), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), s)
     else:
-        L.conv_igemm(dt, L.CONV3, ptr(x0), c0, ptr(x1), c1, ptr(wp), ptr(b), ptr(raw), cout, 0, 0, 0, B, H, W, s)
+        igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, None, B, H, W)
         L.bn_eval_params(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, cout, ptr(bn.mean), ptr(bn.invstd),
                          ptr(bn.scale), ptr(bn.shift), s)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
@@ -194,7 +226,7 @@ class ConvBlockFn(torch.autograd.Function):
         _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
         wp2t = _pack_conv(w2, dt, True)
         da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
-        L.conv_igemm(dt, L.CONV3, ptr(draw2), C, 0, 0, ptr(wp2t), 0, ptr(da1), C, 0, 0, 0, B, H, W, s)
+        igemm(dt, L.CONV3, draw2, C, None, 0, wp2t, None, da1, C, None, 0, None, B, H, W)
         # ---- first conv layer
         draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False)
         dw1 = torch.empty_like(w1)
@@ -208,7 +240,7 @@ class ConvBlockFn(torch.autograd.Function):
             wp1t = _pack_conv(w1, dt, True)
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
             dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
-            L.conv_igemm(dt, L.CONV3, ptr(draw1), C, 0, 0, ptr(wp1t), 0, ptr(dx0), c0, ptr(dx1), c1, 0, B, H, W, s)
+            igemm(dt, L.CONV3, draw1, C, None, 0, wp1t, None, dx0, c0, dx1, c1, None, B, H, W)
         return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None)
 
 
@@ -222,7 +254,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         cout = w.shape[1]
         wp = _pack_convT(w, dt, False)
         y = nhwc_empty(B, cout, 2 * H, 2 * W, x.dtype, x.device)
-        L.conv_igemm(dt, L.CONVT, ptr(x), cin, 0, 0, ptr(wp), ptr(b), ptr(y), cout, 0, 0, 0, B, H, W, _stream())
+        igemm(dt, L.CONVT, x, cin, None, 0, wp, b, y, cout, None, 0, None, B, H, W)
         ctx.save_for_backward(x, w)
         ctx.dt = dt
         return y
@@ -246,7 +278,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _pack_convT(w, dt, True)
             dx = nhwc_empty(B, cin, H, W, x.dtype, dev)
-            L.conv_igemm(dt, L.CONV2S2, ptr(dy), cout, 0, 0, ptr(wpt), 0, ptr(dx), cin, 0, 0, 0, B, H, W, s)
+            igemm(dt, L.CONV2S2, dy, cout, None, 0, wpt, None, dx, cin, None, 0, None, B, H, W)
         return dx, dw, db
 
 
