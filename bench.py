@@ -53,7 +53,13 @@ def cpu_baseline(args):
     import torch
     from oracle.torch_ref import OracleTrainer
 
-    cores = os.cpu_count() or 1
+    # host cores this process may actually use: the scheduler affinity, capped at the per-GPU CPU share
+    # of the box (16) unless HIPSEG_CPU_THREADS overrides it
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("HIPSEG_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     tr = OracleTrainer(args.model)
     g = torch.Generator().manual_seed(0)
@@ -154,7 +160,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
 

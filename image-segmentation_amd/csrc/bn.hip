@@ -29,7 +29,8 @@ __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
 
 // ------------------------------------------------------------------ finalize of the conv-epilogue statistics
 // stats: [mtiles][2][C]; block = 16 channels x 16 tile slices, double accumulation.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int C,
+// rows of the statistics matrix are read at `rstride` (1, or the chunk size after the pre-reduction)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int rstride, int C,
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* running_mean, float* running_var,
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     double S = 0.0, Q = 0.0;
     if (c < C) {
         for (int t = sl; t < mtiles; t += 16) {
-            S += (double)stats[((size_t)t * 2 + 0) * C + c];
-            Q += (double)stats[((size_t)t * 2 + 1) * C + c];
+            S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
+            Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
         }
     }
     sS[sl][cl] = S;
@@ -150,49 +151,56 @@ inline int vec_for(int C, int dtype) {
     return (C % v == 0) ? v : 1;
 }
 
-// g routed through maxpool + relu for one output pixel; fills per-position y>0 / argmax decisions.
+// One output pixel's worth of backward state.  issue() only issues the global loads (so several
+// pixels can be in flight per lane before the first use), finish() routes dy through maxpool + relu.
 // Shared by reduce and apply so both make identical decisions.
 template <typename T, int V, bool POOL>
 struct PixelCtx {
-    float xh[POOL ? 4 : 1][V];  // xhat
-    float g[POOL ? 4 : 1][V];   // routed gradient
-    long ip[POOL ? 4 : 1];
-    __device__ __forceinline__ void load(const T* x, const T* dy, const float (&mean)[V], const float (&invstd)[V],
-                                         const float (&sc)[V], const float (&sh)[V], long op, int cg, int H, int W,
-                                         int C) {
-        float gv[V];
+    static constexpr int NP = POOL ? 4 : 1;
+    float xh[NP][V];  // xhat, after finish()
+    float g[NP][V];   // routed gradient, after finish()
+    float xr[NP][V];  // raw x
+    float gv[V];      // raw dy
+    long ip[NP];
+    __device__ __forceinline__ void issue(const T* x, const T* dy, long op, int cg, int H, int W, int C) {
         ldv<T, V>(dy + op * C + cg * V, gv);
         if (!POOL) {
             ip[0] = op;
-            float v[V];
-            ldv<T, V>(x + op * C + cg * V, v);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                xh[0][e] = (v[e] - mean[e]) * invstd[e];
-                g[0][e] = (v[e] * sc[e] + sh[e] > 0.f) ? gv[e] : 0.f;
-            }
+            ldv<T, V>(x + op * C + cg * V, xr[0]);
         } else {
             const int Ho = H / 2, Wo = W / 2;
             const int xo = (int)(op % Wo);
             const int yo = (int)((op / Wo) % Ho);
             const long n = op / ((long)Wo * Ho);
-            float best[V];
-            int bk[V];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 ip[k] = (n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
-                float v[V];
-                ldv<T, V>(x + ip[k] * C + cg * V, v);
+                ldv<T, V>(x + ip[k] * C + cg * V, xr[k]);
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const float (&mean)[V], const float (&invstd)[V], const float (&sc)[V],
+                                           const float (&sh)[V]) {
+        if (!POOL) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                xh[0][e] = (xr[0][e] - mean[e]) * invstd[e];
+                g[0][e] = (xr[0][e] * sc[e] + sh[e] > 0.f) ? gv[e] : 0.f;
+            }
+        } else {
+            float best[V];
+            int bk[V];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    xh[k][e] = (v[e] - mean[e]) * invstd[e];
-                    const float yv = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                    xh[k][e] = (xr[k][e] - mean[e]) * invstd[e];
+                    const float yv = fmaxf(xr[k][e] * sc[e] + sh[e], 0.f);
                     if (k == 0 || yv > best[e]) {  // first maximum wins (window scan order)
                         best[e] = yv;
                         bk[e] = k;
                     }
                 }
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -227,15 +235,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix_out) end = npix_out;
-        for (long op = start + pl; op < end; op += PL) {
-            PixelCtx<T, V, POOL> ctx;
-            ctx.load(x, dy, mn, is, sc, sh, op, cg, H, W, C);
+        constexpr int UNR = POOL ? 2 : 4;  // pixels in flight per lane
+        for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
+            PixelCtx<T, V, POOL> ctx[UNR];
 #pragma unroll
-            for (int k = 0; k < (POOL ? 4 : 1); ++k)
+            for (int u = 0; u < UNR; ++u)
+                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, op0 + (long)u * PL, cg, H, W, C);
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    s1[e] += ctx.g[k][e];
-                    s2[e] += ctx.g[k][e] * ctx.xh[k][e];
+            for (int u = 0; u < UNR; ++u)
+                if (op0 + (long)u * PL < end) {
+                    ctx[u].finish(mn, is, sc, sh);
+#pragma unroll
+                    for (int k = 0; k < (POOL ? 4 : 1); ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            s1[e] += ctx[u].g[k][e];
+                            s2[e] += ctx[u].g[k][e] * ctx[u].xh[k][e];
+                        }
                 }
         }
     }
@@ -305,19 +321,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix_out) end = npix_out;
-        for (long op = start + pl; op < end; op += PL) {
-            PixelCtx<T, V, POOL> ctx;
-            ctx.load(x, dy, mn, is, sc, sh, op, cg, H, W, C);
+        constexpr int UNR = POOL ? 2 : 4;  // pixels in flight per lane
+        for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
+            PixelCtx<T, V, POOL> ctx[UNR];
 #pragma unroll
-            for (int k = 0; k < (POOL ? 4 : 1); ++k) {
-                float o[V];
+            for (int u = 0; u < UNR; ++u)
+                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, op0 + (long)u * PL, cg, H, W, C);
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    o[e] = sc[e] * (ctx.g[k][e] - k1[e] - ctx.xh[k][e] * k2[e]);
-                    sb[e] += o[e];
+            for (int u = 0; u < UNR; ++u)
+                if (op0 + (long)u * PL < end) {
+                    ctx[u].finish(mn, is, sc, sh);
+#pragma unroll
+                    for (int k = 0; k < (POOL ? 4 : 1); ++k) {
+                        float o[V];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            o[e] = sc[e] * (ctx[u].g[k][e] - k1[e] - ctx[u].xh[k][e] * k2[e]);
+                            sb[e] += o[e];
+                        }
+                        stv<T, V>(dx + ctx[u].ip[k] * C + cg * V, o);
+                    }
                 }
-                stv<T, V>(dx + ctx.ip[k] * C + cg * V, o);
-            }
         }
     }
     if (dbias) {  // conv-bias gradient = per-channel sum of dx (uniform branch)
@@ -392,14 +416,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 }
 
 // out[r][c] = sum_blk partial[blk][r][c]; block = 64 columns x 4 block-slices, fixed order.
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int RC,
-                                                               float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int rstride,
+                                                               int RC, float* __restrict__ out) {
     __shared__ float sm[4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < RC)
-        for (int b = sl; b < nblk; b += 4) s += partial[(size_t)b * RC + c];
+        for (int b = sl; b < nblk; b += 4) s += partial[(size_t)b * rstride * RC + c];
     sm[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && c < RC) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
@@ -430,15 +454,24 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int hipseg_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma,
+extern "C" int hipseg_bn_finalize(float* stats, int mtiles, int C, double count, const float* gamma,
                                   const float* beta, float eps, float momentum, float* running_mean,
                                   float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
                                   float* scale, float* shift, hipseg_stream_t stream) {
     HS_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && C > 0 && mtiles > 0 && count > 0,
                "bn_finalize: bad arguments");
     HS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var mismatch");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rows = mtiles, rstride = 1;
+    if (mtiles > 128) {  // two-stage: chunks of 64 tiles first (many blocks), then the per-channel finish
+        rstride = 64;
+        rows = cdiv(mtiles, rstride);
+        hipLaunchKernelGGL(colreduce_inplace_kernel, dim3(cdiv(2 * C, 64), rows), dim3(256), 0, s, stats, mtiles, 2 * C,
+                           rstride);
+        HS_LAUNCH_CHECK("bn_finalize_stage1");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, stats, rows, rstride, C, count, gamma,
+                       beta, eps, momentum, running_mean, running_var,
                        reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale, shift);
     HS_LAUNCH_CHECK("bn_finalize");
     return HIPSEG_OK;
@@ -540,12 +573,19 @@ extern "C" int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, con
     return HIPSEG_OK;
 }
 
-extern "C" int hipseg_colsum_finalize(const float* partial, int nblk, int rows, int C, float* out,
+extern "C" int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out,
                                       hipseg_stream_t stream) {
     HS_REQUIRE(partial && out && nblk > 0 && rows > 0 && C > 0, "colsum_finalize: bad arguments");
     const int RC = rows * C;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 64)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), partial, nblk, RC, out);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int n = nblk, rstride = 1;
+    if (nblk > 64) {  // two-stage (the partial buffer is clobbered): chunks of 32 blocks first
+        rstride = 32;
+        n = cdiv(nblk, rstride);
+        hipLaunchKernelGGL(colreduce_inplace_kernel, dim3(cdiv(RC, 64), n), dim3(256), 0, s, partial, nblk, RC, rstride);
+        HS_LAUNCH_CHECK("colsum_finalize_stage1");
+    }
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 64)), dim3(256), 0, s, partial, n, rstride, RC, out);
     HS_LAUNCH_CHECK("colsum_finalize");
     return HIPSEG_OK;
 }

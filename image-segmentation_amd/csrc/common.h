@@ -79,3 +79,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---------------------------------------------------------------- shared reduction stage
+// in-place pre-reduction of a [rows][RC] partial matrix: block (column block, chunk j) sums the rows of
+// chunk j (double accumulation) into the chunk's FIRST row.  Deterministic, no extra workspace.
+static __global__ __launch_bounds__(256) void colreduce_inplace_kernel(float* __restrict__ part, int rows, long RC, int chunk) {
+    __shared__ double sm[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * chunk;
+    int r1 = r0 + chunk;
+    if (r1 > rows) r1 = rows;
+    double s = 0.0;
+    if (c < RC)
+        for (int r = r0 + sl; r < r1; r += 4) s += (double)part[(size_t)r * RC + c];
+    sm[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < RC) part[(size_t)r0 * RC + c] = (float)((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]));
+}
+

@@ -14,6 +14,8 @@
 //
 // The epilogue adds the bias, stores NHWC (optionally split over two destination tensors, or
 // pixel-shuffled for ConvTranspose2d) and reduces the per-tile BatchNorm partial sums.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -307,6 +309,267 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 fast path: the same tiling, but both LDS images are filled by LDS-DMA (global_load_lds_dwordx4,
+// no VGPR round trip, no ds_write) into a DOUBLE-BUFFERED LDS ring: the DMA of chunk k+1 is in flight
+// while the MFMAs of chunk k run; one barrier per chunk (the "2-phase" schedule).  An LDS-DMA writes
+// wave-uniform-base + lane*16, which is exactly the [k-octet][pixel][8] / [tap][k-octet][n][8] images;
+// the per-lane SOURCE address does the halo gather, padding pixels read a 16-byte zero word instead.
+// Needs 16-byte aligned channel vectors (C0 % 8 == 0, C1 % 8 == 0).
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+template <int MODE, int BN>
+__global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
+    typedef bf16 T;
+    constexpr int KC = 16, KG = 2;
+    constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
+    constexpr int NPIXP = (NPIX + 63) / 64 * 64;
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;  // 1-KiB DMA pieces per chunk
+    constexpr int NAW = (NA + 3) / 4, NBW = (NB + 3) / 4;    // per wave
+    constexpr int RUNB = BN * 16;                            // bytes of one (tap, k-octet) weight run
+    static_assert(B_BYTES % 1024 == 0 && A_BYTES % 1024 == 0, "whole DMA pieces");
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ntile = blockIdx.x % p.ntn;
+    const int mtile = blockIdx.x / p.ntn;
+    const int tx = mtile % p.tiles_x;
+    const int ty = (mtile / p.tiles_x) % p.tiles_y;
+    const int img = mtile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = ntile * BN;
+    int oy, ox;
+    if (MODE == HIPSEG_CONV3) {
+        oy = y0 - 1;
+        ox = x0 - 1;
+    } else if (MODE == HIPSEG_CONV2S2) {
+        oy = 2 * y0;
+        ox = 2 * x0;
+    } else {
+        oy = y0;
+        ox = x0;
+    }
+    const T* in0 = reinterpret_cast<const T*>(p.in0);
+    const T* in1 = reinterpret_cast<const T*>(p.in1);
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.wp);
+    const T* zero = reinterpret_cast<const T*>(&g_zero16);
+
+    // per-lane source pixel of each of this wave's A pieces (piece = 64 consecutive halo pixels of one octet)
+    long apix[NAW];
+    int aoct[NAW];
+#pragma unroll
+    for (int j = 0; j < NAW; ++j) {
+        const int s = j * 4 + wave;
+        aoct[j] = s / (NPIXP / 64);
+        const int pix = (s % (NPIXP / 64)) * 64 + lane;
+        const int iy = oy + pix / HW, ix = ox + pix % HW;
+        const bool ok = s < NA && pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        apix[j] = ok ? ((long)img * p.Hi + iy) * p.Wi + ix : -1;
+    }
+    const int kgp = p.Kp / 8;
+
+    auto stage = [&](int buf, int c0) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NAW; ++j) {
+            const int s = j * 4 + wave;
+            if (s < NA) {
+                const int c = c0 + aoct[j] * 8;
+                const T* src = zero;
+                if (apix[j] >= 0 && c < p.K) src = (c < p.C0) ? in0 + apix[j] * p.C0 + c : in1 + apix[j] * p.C1 + (c - p.C0);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + s * 1024), 16, 0, 0);
+            }
+        }
+        const int kg0 = c0 / 8;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int s = j * 4 + wave;
+            if (s < NB) {
+                const int b = s * 1024 + lane * 16;
+                const int run = b / RUNB, off = b % RUNB;
+                const int tap = run / KG, kgl = run % KG;
+                const unsigned char* src = wp + (((size_t)tap * kgp + kg0 + kgl) * p.Np + n0) * 16 + off;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + s * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int hbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = r & 15;
+        hbase[i] = MODE == HIPSEG_CONV2S2 ? (2 * py) * HW + 2 * px : py * HW + px;
+    }
+    int ncol[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
+
+    const int nchunks = p.Kp / KC;
+    stage(0, 0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk kc have landed
+        __syncthreads();  // ... everyone's have, and everyone is done reading the other buffer
+        if (kc + 1 < nchunks) stage((kc + 1) & 1, (kc + 1) * KC);
+        const unsigned char* sA = smem + (kc & 1) * BUF;
+        const unsigned char* sB = sA + A_BYTES;
+        // fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue (register double buffer):
+        // with one wave per SIMD nothing else hides the ds_read latency
+        bf16x8 bf[2][NTL], af[2][MT];
+        auto fetch = [&](int slot, int tap) {
+            const int toff = tap_off<MODE>(tap);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                bf[slot][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(tap * KG + h) * BN + ncol[j]) * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)h * NPIXP + hbase[i] + toff) * 16);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            // first half of this tap's MFMAs, then issue the reads of the next tap, then the second half:
+            // the reads get >= MT*NTL/2 MFMA slots (32 cycles each) to land before they are consumed
+            constexpr int HALF = (MT + 1) / 2;
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < NT) fetch((tap + 1) & 1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = HALF; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---------------- epilogue (same as the generic kernel)
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    float ssum[NTL], ssq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        ssum[j] = 0.f;
+        ssq[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int n = n0 + ncol[j];
+        const bool nok = n < p.N;
+        float bv = 0.f;
+        int co = n, ab = 0;
+        if (MODE == HIPSEG_CONVT) {
+            ab = n / p.N0;
+            co = n - ab * p.N0;
+        }
+        if (nok && p.bias) bv = p.bias[co];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int y = y0 + 2 * (wm * MT + i) + (rr >> 4), x = x0 + (rr & 15);
+                if (nok && y < p.H && x < p.W) {
+                    const float v = acc[i][j][e] + bv;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                    if (MODE == HIPSEG_CONVT) {
+                        const long opix = ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+                        out0[opix * p.N0 + co] = (T)v;
+                    } else {
+                        const long opix = ((long)img * p.H + y) * p.W + x;
+                        if (n < p.N0)
+                            out0[opix * p.N0 + n] = (T)v;
+                        else
+                            out1[opix * p.N1 + (n - p.N0)] = (T)v;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            ssum[j] += __shfl_xor(ssum[j], 32, 64);
+            ssq[j] += __shfl_xor(ssq[j], 32, 64);
+        }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
+                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                S += red[(w * 2 + 0) * BN + tid];
+                Q += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
+            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
+        }
+    }
+}
+
+template <int MODE, int BN>
+int launch_dma(const ConvArgs& a, hipStream_t s) {
+    constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
+    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    HS_LAUNCH_CHECK("conv_igemm_dma");
+    return HIPSEG_OK;
+}
+
+template <int MODE>
+int launch_dma_bn(const ConvArgs& a, int bn, hipStream_t s) {
+    if (bn == 128) return launch_dma<MODE, 128>(a, s);
+    if (bn == 64) return launch_dma<MODE, 64>(a, s);
+    return launch_dma<MODE, 32>(a, s);
+}
+
+int launch_dma_mode(const ConvArgs& a, int mode, int bn, hipStream_t s) {
+    switch (mode) {
+        case HIPSEG_CONV3: return launch_dma_bn<HIPSEG_CONV3>(a, bn, s);
+        case HIPSEG_CONV1: return launch_dma_bn<HIPSEG_CONV1>(a, bn, s);
+        case HIPSEG_CONV2S2: return launch_dma_bn<HIPSEG_CONV2S2>(a, bn, s);
+        default: return launch_dma_bn<HIPSEG_CONVT>(a, bn, s);
+    }
+}
+
 template <typename T, int MODE, int BN>
 int launch(const ConvArgs& a, hipStream_t s) {
     constexpr int KC = KT<T>::KC;
@@ -389,6 +652,10 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
     a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == HIPSEG_BF16) return launch_mode<bf16>(a, mode, bn, s);
+    if (dtype == HIPSEG_BF16) {
+        static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
+        if (a.vec_ok && !no_dma) return launch_dma_mode(a, mode, bn, s);
+        return launch_mode<bf16>(a, mode, bn, s);
+    }
     return launch_mode<float>(a, mode, bn, s);
 }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
 }
 
 // sum the S slabs in fixed order and scatter into the parameter's native layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, int NT,
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, int sstep, int NT,
                                     int CU, int CV, int CUp, int CVp, int mode, int ab) {
     const long total = (long)NT * CU * CV;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -215,7 +215,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
         const int u = (int)((i / CV) % CU);
         const int t = (int)(i / ((long)CV * CU));
         const size_t off = ((size_t)t * CUp + u) * CVp + v;
-        const size_t stride = (size_t)NT * CUp * CVp;
+        const size_t stride = (size_t)NT * CUp * CVp * sstep;
         float sum = 0.f;
         for (int s = 0; s < S; ++s) sum += slabs[off + s * stride];
         size_t o;
@@ -226,6 +226,35 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
         else
             o = ((size_t)v * CU + u) * 4 + ab;  // ConvT (Cin=v, Cout=u, a, b)
         dw[o] = sum;
+    }
+}
+
+// 3x3 case: 16(u) x 16(v) x 9 tile per block.  Slab reads are 64-byte runs along v; the tile is turned in
+// LDS so the native (Cout=v, Cin=u, ky, kx) write is 576-byte runs (144 consecutive floats per v).
+__global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                             int S, int sstep, int CU, int CV, int CUp, int CVp) {
+    __shared__ float tile[16 * 16 * 9];
+    const int tid = threadIdx.x;
+    const int u = tid >> 4, v = tid & 15;
+    const int u0 = blockIdx.y * 16, v0 = blockIdx.x * 16;
+    const size_t tstride = (size_t)CUp * CVp, sstride = 9 * tstride * sstep;
+    const float* src = slabs + (size_t)(u0 + u) * CVp + v0 + v;  // padded: always in bounds
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += src[s * sstride + t * tstride];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tile[(v * 16 + u) * 9 + t] = acc[t];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int idx = k * 256 + tid;
+        const int vv = idx / 144, rem = idx % 144;
+        const int uu = rem / 9, t = rem % 9;
+        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t] = tile[idx];
     }
 }
 
@@ -244,7 +273,7 @@ Plan make_plan(int mode, int CU, int CV, int B, int H, int W) {
     p.tiles_x = cdiv(W, TW);
     p.tiles_y = cdiv(H, WT<T>::TH);
     p.ntiles = B * p.tiles_x * p.tiles_y;
-    int S = 1024 / (p.UT * p.VT);
+    int S = 512 / (p.UT * p.VT);  // ~2 workgroups per CU; fewer, fatter splits keep the slab traffic small
     if (S < 1) S = 1;
     if (S > p.ntiles) S = p.ntiles;
     p.S = S;
@@ -334,8 +363,23 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
         else
             rc = pl.NT == 9 ? launch<float, 9>(a, s) : launch<float, 1>(a, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slabs, dw, pl.S, pl.NT, CU, CV,
-                           pl.CUp, pl.CVp, mode, ab);
+        // many splits of a small weight tensor: pre-reduce chunks of 16 slabs in place (wide grid), then
+        // the (transposing) final pass walks the chunk heads only
+        int S = pl.S, sstep = 1;
+        if (pl.S >= 32) {
+            sstep = 16;
+            S = cdiv(pl.S, sstep);
+            const long E = (long)pl.NT * pl.CUp * pl.CVp;
+            hipLaunchKernelGGL(colreduce_inplace_kernel, dim3((unsigned)cdiv(E, 64), S), dim3(256), 0, s, slabs, pl.S, E,
+                               sstep);
+            HS_LAUNCH_CHECK("wgrad_prereduce");
+        }
+        if (mode == HIPSEG_CONV3)
+            hipLaunchKernelGGL(wgrad_reduce3_kernel, dim3(cdiv(CV, 16), cdiv(CU, 16)), dim3(256), 0, s, slabs, dw, S,
+                               sstep, CU, CV, pl.CUp, pl.CVp);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slabs, dw, S, sstep, pl.NT, CU, CV,
+                               pl.CUp, pl.CVp, mode, ab);
         HS_LAUNCH_CHECK("wgrad_reduce");
     }
     return HIPSEG_OK;

@@ -124,17 +124,20 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 }
 
 // dw[co][ci], db[co] from partial[blk][Cin+1][Cout]
-__global__ void stem_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin, int Cout,
-                                         float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (Cin + 1) * Cout) return;
+// one 64-thread block per output element: lanes stride over the block partials, fixed-order wave sum
+__global__ __launch_bounds__(64) void stem_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin,
+                                                                int Cout, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x;
     const int row = i / Cout, co = i % Cout;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * (Cin + 1) + row) * Cout + co];
-    if (row < Cin)
-        dw[co * Cin + row] = s;
-    else
-        db[co] = s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[((size_t)b * (Cin + 1) + row) * Cout + co];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        if (row < Cin)
+            dw[co * Cin + row] = s;
+        else
+            db[co] = s;
+    }
 }
 
 // ------------------------------------------------------------------ head: NHWC -> NCHW fp32 logits
@@ -246,17 +249,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     }
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin, int Cout,
-                                         float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Cout * (Cin + 1)) return;
+__global__ __launch_bounds__(64) void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int Cin,
+                                                                int Cout, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x;
     const int co = i / (Cin + 1), c = i % (Cin + 1);
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * Cout * (Cin + 1) + i];
-    if (c < Cin)
-        dw[co * Cin + c] = s;
-    else
-        db[co] = s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * Cout * (Cin + 1) + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        if (c < Cin)
+            dw[co * Cin + c] = s;
+        else
+            db[co] = s;
+    }
 }
 
 // ------------------------------------------------------------------ bilinear, align_corners=True
@@ -447,8 +452,8 @@ extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float*
                            HW, Cout, g.CG, g.PL, g.ppb);
     });
     HS_LAUNCH_CHECK("stem_bwd");
-    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(cdiv((Cin + 1) * Cout, 256)), dim3(256), 0, s, partial, g.nblk,
-                       Cin, Cout, dw, db);
+    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3((Cin + 1) * Cout), dim3(64), 0, s, partial, g.nblk, Cin, Cout, dw,
+                       db);
     HS_LAUNCH_CHECK("stem_bwd_finalize");
     return HIPSEG_OK;
 }
@@ -494,8 +499,8 @@ extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, c
                            partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb);
     });
     HS_LAUNCH_CHECK("head_bwd");
-    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, s, partial, g.nblk,
-                       Cin, Cout, dw, db);
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(Cout * (Cin + 1)), dim3(64), 0, s, partial, g.nblk, Cin, Cout, dw,
+                       db);
     HS_LAUNCH_CHECK("head_bwd_finalize");
     return HIPSEG_OK;
 }

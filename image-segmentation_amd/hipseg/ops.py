@@ -192,9 +192,17 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool):
                     B, H, W, C, int(pool), s)
     L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), s)
     draw = nhwc_empty(B, C, H, W, raw.dtype, dev)
-    dbias = torch.zeros(C, dtype=torch.float32, device=dev)
     L.bn_bwd_apply(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
-                   float(B * H * W), 0 if train else 1, ptr(draw), ptr(dbias), B, H, W, C, int(pool), s)
+                   float(B * H * W), 0 if train else 1, ptr(draw), 0, B, H, W, C, int(pool), s)
+    if train:
+        # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
+        # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8)
+        dbias = torch.zeros(C, dtype=torch.float32, device=dev)
+    else:
+        dbias = _f32(C, dev)
+        npix = B * H * W
+        part = _f32(L.colsum_blocks(npix, C, dt) * C, dev)
+        L.colsum(dt, ptr(draw), npix, C, ptr(part), ptr(dbias), s)
     return draw, sums[C:], sums[:C], dbias
 
 

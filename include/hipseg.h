@@ -107,7 +107,7 @@ int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* 
  *   num_batches_tracked += 1 when the pointers are non-NULL.  count = B*H*W.
  * bn_eval_params: scale/shift/mean/invstd from running statistics.
  * (nn.BatchNorm2d, models/processing_blocks.py:44,47; eps 1e-5, momentum 0.1) */
-int hipseg_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma,
+int hipseg_bn_finalize(float* stats, int mtiles, int C, double count, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t* num_batches_tracked, float* mean,
                        float* invstd, float* scale, float* shift, hipseg_stream_t stream);
@@ -134,8 +134,9 @@ int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* m
                         const float* sums, double count, int eval, void* dx, float* dbias, int B,
                         int H, int W, int C, int pool, hipseg_stream_t stream);
 
-/* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic). */
-int hipseg_colsum_finalize(const float* partial, int nblk, int rows, int C, float* out,
+/* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic).  The partial
+ * workspace is clobbered (in-place tree).  bn_finalize likewise clobbers its `stats` workspace. */
+int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out,
                            hipseg_stream_t stream);
 /* per-channel sum over pixels of an NHWC tensor: out[c] = sum_p x[p][c] (bias gradients). */
 int hipseg_colsum_blocks(long npix, int C, int dtype);

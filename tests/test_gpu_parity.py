@@ -147,6 +147,10 @@ def test_models_fp32_vs_reference_golden(M, golden, tag, arch, key, shape):
     for k, p in m.named_parameters():
         s = g[f"{tag}/gradstat/{k}"]
         gd = p.grad.double()
+        if k.endswith(("conv.0.bias", "conv.3.bias")):
+            # conv bias in front of train-mode BN: exactly 0 here, ~1e-6 of rounding noise in the reference
+            assert float(gd.abs().sum()) <= 1e-4 and s[1] <= 1e-4, k
+            continue
         mine = np.array([float(gd.abs().sum()), float(gd.pow(2).sum())])
         np.testing.assert_allclose(mine, s[1:], rtol=5e-3, atol=1e-6, err_msg=k)
         gk = f"{tag}/grad/{k}"
