@@ -29,34 +29,38 @@ __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
 
 // ------------------------------------------------------------------ finalize of the conv-epilogue statistics
 // stats: [mtiles][2][C]; block = 16 channels x 16 tile slices, double accumulation.
-// rows of the statistics matrix are read at `rstride` (1, or the chunk size after the pre-reduction)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int rstride, int C,
+// stats: [mtiles][2][C].  One launch: block = 4 channels x 64 tile slices (each lane sums <= mtiles/64 rows,
+// all loads independent), double accumulation, LDS tree over the slices, then the per-channel finish.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int C,
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* running_mean, float* running_var,
                                                            long long* nbt, float* mean, float* invstd, float* scale,
                                                            float* shift) {
-    __shared__ double sS[16][17], sQ[16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sS[64][4], sQ[64][4];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double S = 0.0, Q = 0.0;
     if (c < C) {
-        for (int t = sl; t < mtiles; t += 16) {
-            S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
-            Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
+#pragma unroll 4
+        for (int t = sl; t < mtiles; t += 64) {
+            S += (double)stats[((size_t)t * 2 + 0) * C + c];
+            Q += (double)stats[((size_t)t * 2 + 1) * C + c];
         }
     }
     sS[sl][cl] = S;
     sQ[sl][cl] = Q;
     __syncthreads();
-    if (sl == 0 && c < C) {
-        S = 0.0;
-        Q = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            S += sS[i][cl];
-            Q += sQ[i][cl];
+    for (int o = 32; o > 0; o >>= 1) {
+        if (sl < o) {
+            sS[sl][cl] += sS[sl + o][cl];
+            sQ[sl][cl] += sQ[sl + o][cl];
         }
+        __syncthreads();
+    }
+    if (sl == 0 && c < C) {
+        S = sS[0][cl];
+        Q = sQ[0][cl];
         const double m = S / count;
         double var = Q / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -415,18 +419,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 
-// out[r][c] = sum_blk partial[blk][r][c]; block = 64 columns x 4 block-slices, fixed order.
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int rstride,
-                                                               int RC, float* __restrict__ out) {
-    __shared__ float sm[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// out[r][c] = sum_blk partial[blk][r][c]; block = 16 columns x 16 block-slices, fixed order, one launch.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int RC,
+                                                               float* __restrict__ out) {
+    __shared__ float sm[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < RC)
-        for (int b = sl; b < nblk; b += 4) s += partial[(size_t)b * rstride * RC + c];
+    if (c < RC) {
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += 16) s += partial[(size_t)b * RC + c];
+    }
     sm[sl][cl] = s;
     __syncthreads();
-    if (sl == 0 && c < RC) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+    if (sl == 0 && c < RC) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sm[i][cl];
+        out[c] = t;
+    }
 }
 
 #define DISPATCH_TV(dtype, V, ...)                              \
@@ -461,17 +472,8 @@ extern "C" int hipseg_bn_finalize(float* stats, int mtiles, int C, double count,
     HS_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && C > 0 && mtiles > 0 && count > 0,
                "bn_finalize: bad arguments");
     HS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var mismatch");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rows = mtiles, rstride = 1;
-    if (mtiles > 128) {  // two-stage: chunks of 64 tiles first (many blocks), then the per-channel finish
-        rstride = 64;
-        rows = cdiv(mtiles, rstride);
-        hipLaunchKernelGGL(colreduce_inplace_kernel, dim3(cdiv(2 * C, 64), rows), dim3(256), 0, s, stats, mtiles, 2 * C,
-                           rstride);
-        HS_LAUNCH_CHECK("bn_finalize_stage1");
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, stats, rows, rstride, C, count, gamma,
-                       beta, eps, momentum, running_mean, running_var,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats,
+                       mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var,
                        reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale, shift);
     HS_LAUNCH_CHECK("bn_finalize");
     return HIPSEG_OK;
@@ -577,15 +579,8 @@ extern "C" int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C,
                                       hipseg_stream_t stream) {
     HS_REQUIRE(partial && out && nblk > 0 && rows > 0 && C > 0, "colsum_finalize: bad arguments");
     const int RC = rows * C;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int n = nblk, rstride = 1;
-    if (nblk > 64) {  // two-stage (the partial buffer is clobbered): chunks of 32 blocks first
-        rstride = 32;
-        n = cdiv(nblk, rstride);
-        hipLaunchKernelGGL(colreduce_inplace_kernel, dim3(cdiv(RC, 64), n), dim3(256), 0, s, partial, nblk, RC, rstride);
-        HS_LAUNCH_CHECK("colsum_finalize_stage1");
-    }
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 64)), dim3(256), 0, s, partial, n, rstride, RC, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       partial, nblk, RC, out);
     HS_LAUNCH_CHECK("colsum_finalize");
     return HIPSEG_OK;
 }

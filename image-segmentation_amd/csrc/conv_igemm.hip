@@ -75,6 +75,144 @@ __device__ __forceinline__ constexpr int tap_off(int tap) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Shared epilogue.  The MFMA accumulator layout puts one output CHANNEL on each lane, so direct stores
+// would be 2-byte scattered stores (a dozen times slower per byte than 16-byte ones).  Each wave
+// instead turns its 32-pixel x (32*NTL)-channel sub-tile through a private LDS tile (fp32) and
+// writes full 16-byte channel vectors per lane: 128 contiguous bytes per pixel for a 64-channel wave tile.
+// Also adds the bias and reduces the BatchNorm partial statistics (sum, sum of squares per channel).
+template <typename T, int MODE, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[(BM / (4 / (BN >= 64 ? 2 : 1))) / 32]
+                                                                                 [(BN / (BN >= 64 ? 2 : 1)) / 32],
+                                              unsigned char* smem, int mtile, int img, int y0, int x0, int n0) {
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int TN = 32 * NTL;            // channels of the wave tile
+    constexpr int VEC = VecOf<T>::N;        // channels per 16-byte store
+    constexpr int VPR = TN / VEC;           // vectors per pixel row
+    constexpr int NIT = 32 * VPR / 64;      // store iterations per sub-tile (>= 1)
+    static_assert(32 * VPR % 64 == 0, "whole wave iterations");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+
+    __syncthreads();  // every wave is done with the staging buffers: LDS becomes the transpose scratch
+    float* tile = reinterpret_cast<float*>(smem) + wave * (32 * TN);
+
+    float bv[NTL], ssum[NTL], ssq[NTL];
+    int ncol[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        ncol[j] = wn * (BN / WN) + j * 32 + r;
+        const int n = n0 + ncol[j];
+        int co = n;
+        if (MODE == HIPSEG_CONVT) co = n % p.N0;
+        bv[j] = (n < p.N && p.bias) ? p.bias[co] : 0.f;
+        ssum[j] = 0.f;
+        ssq[j] = 0.f;
+    }
+    // vector path needs every 8(4)-channel group to stay inside one destination tensor / tap group
+    const bool vec_ok = (p.N0 % VEC == 0) && (p.N1 % VEC == 0);
+    const int nw0 = n0 + wn * (BN / WN);  // first channel of this wave's tile
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int yb = y0 + 2 * (wm * MT + i);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const bool nok = n0 + ncol[j] < p.N;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float v = acc[i][j][e] + bv[j];
+                tile[rr * TN + j * 32 + r] = v;
+                if (nok && yb + (rr >> 4) < p.H && x0 + (rr & 15) < p.W) {
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int v = it * 64 + lane;
+            const int rr = v / VPR, cv = v % VPR;
+            const int y = yb + (rr >> 4), x = x0 + (rr & 15);
+            const int n = nw0 + cv * VEC;
+            if (y < p.H && x < p.W && n < p.N) {
+                const float* src = tile + rr * TN + cv * VEC;
+                if (vec_ok) {
+                    typename VecOf<T>::type o;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o[q] = (T)src[q];
+                    T* dst;
+                    if (MODE == HIPSEG_CONVT) {
+                        const int ab = n / p.N0, co = n - ab * p.N0;
+                        const long opix = ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+                        dst = out0 + opix * p.N0 + co;
+                    } else {
+                        const long opix = ((long)img * p.H + y) * p.W + x;
+                        dst = (n < p.N0) ? out0 + opix * p.N0 + n : out1 + opix * p.N1 + (n - p.N0);
+                    }
+                    *reinterpret_cast<typename VecOf<T>::type*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const int nn = n + q;
+                        if (nn < p.N) {
+                            if (MODE == HIPSEG_CONVT) {
+                                const int ab = nn / p.N0, co = nn - ab * p.N0;
+                                const long opix =
+                                    ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+                                out0[opix * p.N0 + co] = (T)src[q];
+                            } else {
+                                const long opix = ((long)img * p.H + y) * p.W + x;
+                                if (nn < p.N0)
+                                    out0[opix * p.N0 + nn] = (T)src[q];
+                                else
+                                    out1[opix * p.N1 + (nn - p.N0)] = (T)src[q];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            ssum[j] += __shfl_xor(ssum[j], 32, 64);
+            ssq[j] += __shfl_xor(ssq[j], 32, 64);
+        }
+        __syncthreads();  // transpose tiles are dead: reuse LDS for the cross-wave reduction
+        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
+                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                S += red[(w * 2 + 0) * BN + tid];
+                Q += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
+            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
+        }
+    }
+}
+
 template <typename T, int MODE, int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int G = KT<T>::G, KC = KT<T>::KC, KG = KC / G;
@@ -236,77 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
-    // ---------------- epilogue: bias, store, BN partial statistics
-    T* out0 = reinterpret_cast<T*>(p.out0);
-    T* out1 = reinterpret_cast<T*>(p.out1);
-    float ssum[NTL], ssq[NTL];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        ssum[j] = 0.f;
-        ssq[j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        const int n = n0 + ncol[j];
-        const bool nok = n < p.N;
-        float bv = 0.f;
-        int co = n, ab = 0;
-        if (MODE == HIPSEG_CONVT) {
-            ab = n / p.N0;
-            co = n - ab * p.N0;
-        }
-        if (nok && p.bias) bv = p.bias[co];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // row inside the 32-pixel sub-tile
-                const int y = y0 + 2 * (wm * MT + i) + (rr >> 4), x = x0 + (rr & 15);
-                if (nok && y < p.H && x < p.W) {
-                    const float v = acc[i][j][e] + bv;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
-                    if (MODE == HIPSEG_CONVT) {
-                        const long opix = ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-                        out0[opix * p.N0 + co] = (T)v;
-                    } else {
-                        const long opix = ((long)img * p.H + y) * p.W + x;
-                        if (n < p.N0)
-                            out0[opix * p.N0 + n] = (T)v;
-                        else
-                            out1[opix * p.N1 + (n - p.N0)] = (T)v;
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 32, 64);
-            ssq[j] += __shfl_xor(ssq[j], 32, 64);
-        }
-        __syncthreads();  // LDS is re-used as the cross-wave scratch
-        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
-        if (h == 0) {
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
-                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-            float S = 0.f, Q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                S += red[(w * 2 + 0) * BN + tid];
-                Q += red[(w * 2 + 1) * BN + tid];
-            }
-            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
-            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
-        }
-    }
+    conv_epilogue<T, MODE, BN>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -465,83 +533,15 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
         }
     }
 
-    // ---------------- epilogue (same as the generic kernel)
-    T* out0 = reinterpret_cast<T*>(p.out0);
-    T* out1 = reinterpret_cast<T*>(p.out1);
-    float ssum[NTL], ssq[NTL];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        ssum[j] = 0.f;
-        ssq[j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        const int n = n0 + ncol[j];
-        const bool nok = n < p.N;
-        float bv = 0.f;
-        int co = n, ab = 0;
-        if (MODE == HIPSEG_CONVT) {
-            ab = n / p.N0;
-            co = n - ab * p.N0;
-        }
-        if (nok && p.bias) bv = p.bias[co];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int y = y0 + 2 * (wm * MT + i) + (rr >> 4), x = x0 + (rr & 15);
-                if (nok && y < p.H && x < p.W) {
-                    const float v = acc[i][j][e] + bv;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
-                    if (MODE == HIPSEG_CONVT) {
-                        const long opix = ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-                        out0[opix * p.N0 + co] = (T)v;
-                    } else {
-                        const long opix = ((long)img * p.H + y) * p.W + x;
-                        if (n < p.N0)
-                            out0[opix * p.N0 + n] = (T)v;
-                        else
-                            out1[opix * p.N1 + (n - p.N0)] = (T)v;
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 32, 64);
-            ssq[j] += __shfl_xor(ssq[j], 32, 64);
-        }
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
-        if (h == 0) {
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
-                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-            float S = 0.f, Q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                S += red[(w * 2 + 0) * BN + tid];
-                Q += red[(w * 2 + 1) * BN + tid];
-            }
-            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
-            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
-        }
-    }
+    conv_epilogue<bf16, MODE, BN>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 template <int MODE, int BN>
 int launch_dma(const ConvArgs& a, hipStream_t s) {
     constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16);
+    constexpr size_t ring = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16);
+    constexpr size_t scratch = (size_t)4 * 32 * (BN / (BN >= 64 ? 2 : 1)) * sizeof(float);  // epilogue transpose tiles
+    constexpr size_t lds = ring > scratch ? ring : scratch;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN>),
@@ -575,8 +575,9 @@ int launch(const ConvArgs& a, hipStream_t s) {
     constexpr int KC = KT<T>::KC;
     constexpr int NPIX = Geo<MODE>::HH * Geo<MODE>::HW, NT = Geo<MODE>::NT;
     size_t lds = (size_t)(KC * NPIX + NT * KC * BN) * sizeof(T);
-    const size_t red = (size_t)4 * 2 * BN * sizeof(float);
-    if (lds < red) lds = red;
+    constexpr int WN = BN >= 64 ? 2 : 1;
+    const size_t scratch = (size_t)4 * 32 * (BN / WN) * sizeof(float);  // per-wave fp32 transpose tiles (epilogue)
+    if (lds < scratch) lds = scratch;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BN>), dim3((unsigned)grid), dim3(256), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm");

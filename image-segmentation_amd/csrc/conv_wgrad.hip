@@ -9,6 +9,8 @@
 // A workgroup owns one (u-tile, v-tile) pair for ALL taps (9 accumulator tiles per wave for a 3x3
 // conv) and walks a strided subset of the 16x16 pixel tiles; partial results go to fp32 slabs that a
 // second kernel sums in fixed order into the parameter's native layout (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -206,6 +208,164 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 fast path: LDS images filled by LDS-DMA (global_load_lds_dwordx4) into a double-buffered ring,
+// the next pixel tile streams in while the MFMAs of the current one run (one barrier per tile).
+// A 1-KiB DMA piece = 8 pixel rows x 128 B; the XOR swizzle of the image is applied to the per-lane
+// SOURCE chunk (LDS destination stays linear), out-of-image / padded channels read a zero word.
+__device__ uint4 g_wg_zero16 = {0u, 0u, 0u, 0u};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
+    typedef bf16 T;
+    constexpr int TH = 16, UC = 64, VC = 64, WV = 2;
+    constexpr int HALO = NT == 9 ? 1 : 0;
+    constexpr int PHW = TW + 2 * HALO, NPP = (TH + 2 * HALO) * PHW, NPQ = TH * TW;
+    constexpr int NPP8 = (NPP + 7) / 8 * 8;            // P image padded to whole 8-pixel DMA pieces
+    constexpr int PP_BYTES = NPP8 * 128, Q_BYTES = NPQ * 128, BUF = PP_BYTES + Q_BYTES;
+    constexpr int NPC_P = NPP8 / 8, NPC_Q = NPQ / 8, NPC = NPC_P + NPC_Q;
+    constexpr int NPW = (NPC + 3) / 4;                 // pieces per wave
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int wu = wave / WV, wv = wave % WV;
+    const int vt = blockIdx.x % a.VT;
+    const int ut = (blockIdx.x / a.VT) % a.UT;
+    const int s = blockIdx.x / (a.VT * a.UT);
+    const int u0 = ut * UC, v0 = vt * VC;
+    const T* p0 = reinterpret_cast<const T*>(a.p0);
+    const T* p1 = reinterpret_cast<const T*>(a.p1);
+    const T* q = reinterpret_cast<const T*>(a.q);
+    const T* zero = reinterpret_cast<const T*>(&g_wg_zero16);
+
+    // this lane's (pixel-in-image, source channel chunk) for each of its wave's pieces
+    const int prow = lane >> 3, pchunk = lane & 7;
+    int lpix[NPW], lch[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int pc = j * 4 + wave;
+        const int pix = (pc < NPC_P ? pc : pc - NPC_P) * 8 + prow;  // pixel index inside the P or Q image
+        lpix[j] = pix;
+        lch[j] = (pchunk ^ (((pix >> 1) & 1) << 2)) * 8;  // swizzled source chunk -> first channel
+    }
+
+    auto stage = [&](int buf, int tile) {
+        const int tx = tile % a.tiles_x;
+        const int ty = (tile / a.tiles_x) % a.tiles_y;
+        const int img = tile / (a.tiles_x * a.tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int pc = j * 4 + wave;
+            if (pc < NPC_P) {
+                const int pix = lpix[j];
+                const int gy = y0 + pix / PHW - HALO, gx = x0 + pix % PHW - HALO;
+                const int c = u0 + lch[j];
+                const T* src = zero;
+                if (pix < NPP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.CU) {
+                    const long pixoff = ((long)img * a.PH + a.ps * gy + a.pa) * a.PW + a.ps * gx + a.pb;
+                    src = (c < a.CU0) ? p0 + pixoff * a.CU0 + c : p1 + pixoff * a.CU1 + (c - a.CU0);
+                }
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
+            } else if (pc < NPC) {
+                const int pix = lpix[j];
+                const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+                const int c = v0 + lch[j];
+                const T* src = zero;
+                if (gy < a.H && gx < a.W && c < a.CV) src = q + (((long)img * a.H + gy) * a.W + gx) * a.CV + c;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + PP_BYTES + (pc - NPC_P) * 1024), 16,
+                                                 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // transposed-read lane geometry (see wgrad_kernel)
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int chA = wu * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
+    const int chB = wv * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
+    const int kx0 = 8 * h + tq;
+
+    int buf = 0;
+    if (s < a.ntiles) stage(0, s);
+    for (int tile = s; tile < a.ntiles; tile += a.S) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + a.S < a.ntiles) stage(buf ^ 1, tile + a.S);
+        const bf16* sP = reinterpret_cast<const bf16*>(smem + buf * BUF);
+        const bf16* sQ = reinterpret_cast<const bf16*>(smem + buf * BUF + PP_BYTES);
+
+        bf16x8 bfr[2], afr[2][NT];
+        auto fetch = [&](int slot, int y) {
+            const int q0 = y * TW + kx0, q1 = q0 + 4;
+            const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q0 * 64 + (chB ^ swz<T>(q0))));
+            const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q1 * 64 + (chB ^ swz<T>(q1))));
+            bfr[slot] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ky = NT == 9 ? t / 3 : 0, kx = NT == 9 ? t % 3 : 0;
+                const int a0 = (y + ky) * PHW + kx0 + kx, a1 = a0 + 4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
+                afr[slot][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        constexpr int FIRST = (NT + 1) / 2;
+        fetch(0, 0);
+#pragma unroll
+        for (int y = 0; y < TH; ++y) {
+#pragma unroll
+            for (int t = 0; t < FIRST; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[y & 1][t], bfr[y & 1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (y + 1 < TH) fetch((y + 1) & 1, y + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = FIRST; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[y & 1][t], bfr[y & 1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
+            a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
+        }
+    }
+}
+
+template <int NT>
+int launch_dma(const WgArgs& a, hipStream_t s) {
+    constexpr int HALO = NT == 9 ? 1 : 0;
+    constexpr int NPP8 = ((16 + 2 * HALO) * (TW + 2 * HALO) + 7) / 8 * 8;
+    constexpr size_t lds = 2 * (size_t)(NPP8 * 128 + 16 * TW * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_dma_kernel<NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(256), lds, s, a);
+    HS_LAUNCH_CHECK("conv_wgrad_dma");
+    return HIPSEG_OK;
+}
+
 // sum the S slabs in fixed order and scatter into the parameter's native layout
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, int sstep, int NT,
                                     int CU, int CV, int CUp, int CVp, int mode, int ab) {
@@ -273,7 +433,9 @@ Plan make_plan(int mode, int CU, int CV, int B, int H, int W) {
     p.tiles_x = cdiv(W, TW);
     p.tiles_y = cdiv(H, WT<T>::TH);
     p.ntiles = B * p.tiles_x * p.tiles_y;
-    int S = 512 / (p.UT * p.VT);  // ~2 workgroups per CU; fewer, fatter splits keep the slab traffic small
+    // workgroups per launch ~ CUs (bf16: the double-buffered DMA kernel runs one 146-KB workgroup per CU;
+    // f32: two single-buffered ones).  Fewer, fatter splits also keep the slab traffic small.
+    int S = (sizeof(T) == 2 ? 256 : 512) / (p.UT * p.VT);
     if (S < 1) S = 1;
     if (S > p.ntiles) S = p.ntiles;
     p.S = S;
@@ -358,7 +520,10 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
         a.pa = ab >> 1;
         a.pb = ab & 1;
         int rc;
-        if (dtype == HIPSEG_BF16)
+        static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;
+        if (dtype == HIPSEG_BF16 && a.vec_ok_p && a.vec_ok_q && !no_dma)
+            rc = pl.NT == 9 ? launch_dma<9>(a, s) : launch_dma<1>(a, s);
+        else if (dtype == HIPSEG_BF16)
             rc = pl.NT == 9 ? launch<bf16, 9>(a, s) : launch<bf16, 1>(a, s);
         else
             rc = pl.NT == 9 ? launch<float, 9>(a, s) : launch<float, 1>(a, s);
