@@ -66,7 +66,29 @@ struct ConvArgs {
     int K, Kp, N, Np;
     int tiles_x, tiles_y, ntn;
     int vec_ok;
+    int debug;  // ablation bits (HIPSEG_IGEMM_DEBUG): 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip epilogue
 };
+
+// Wave grid of a workgroup.  The generic kernel runs 4 waves; the DMA kernel runs 8 waves (two per SIMD, so
+// one wave's LDS / barrier waits hide behind the other's MFMAs) on the 256x128 tile.
+template <int BN, int NW>
+struct WG {
+    static constexpr int WN = BN >= 64 ? 2 : 1, WM = NW / WN;
+    static constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+};
+
+// M sub-tile (32 MFMA rows) -> tile pixels: rows 0-15 = 16 pixels of tile row 2s, rows 16-31 = tile row 2s+1
+// ROTATED by ROT pixels, ROT = halo pitch mod 16.  With the rotation the two 16-lane halves of an operand
+// read land on the same 16 LDS slots modulo 16 (conflict-free ds_read_b128 / ds_read_b32); without it a
+// 3x3 halo pitch of 18 gives every read a 2-way bank conflict.
+template <int MODE>
+struct Rot {
+    static constexpr int value = (MODE == HIPSEG_CONV3) ? (Geo<MODE>::HW % 16) : 0;
+};
+template <int MODE>
+__device__ __forceinline__ int sub_px(int rr) {  // pixel column (0..15) of sub-tile row rr
+    return (rr >> 4) ? (((rr & 15) - Rot<MODE>::value) & 15) : (rr & 15);
+}
 
 template <int MODE>
 __device__ __forceinline__ constexpr int tap_off(int tap) {
@@ -81,12 +103,11 @@ __device__ __forceinline__ constexpr int tap_off(int tap) {
 // instead turns its 32-pixel x (32*NTL)-channel sub-tile through a private LDS tile (fp32) and
 // writes full 16-byte channel vectors per lane: 128 contiguous bytes per pixel for a 64-channel wave tile.
 // Also adds the bias and reduces the BatchNorm partial statistics (sum, sum of squares per channel).
-template <typename T, int MODE, int BN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[(BM / (4 / (BN >= 64 ? 2 : 1))) / 32]
-                                                                                 [(BN / (BN >= 64 ? 2 : 1)) / 32],
+template <typename T, int MODE, int BN, int NW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[WG<BN, NW>::MT][WG<BN, NW>::NTL],
                                               unsigned char* smem, int mtile, int img, int y0, int x0, int n0) {
-    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
-    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int WN = WG<BN, NW>::WN, WM = WG<BN, NW>::WM;
+    constexpr int MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
     constexpr int TN = 32 * NTL;            // channels of the wave tile
     constexpr int VEC = VecOf<T>::N;        // channels per 16-byte store
     constexpr int VPR = TN / VEC;           // vectors per pixel row
@@ -129,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[(
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const float v = acc[i][j][e] + bv[j];
                 tile[rr * TN + j * 32 + r] = v;
-                if (nok && yb + (rr >> 4) < p.H && x0 + (rr & 15) < p.W) {
+                if (nok && yb + (rr >> 4) < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                     ssum[j] += v;
                     ssq[j] += v * v;
                 }
@@ -141,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[(
         for (int it = 0; it < NIT; ++it) {
             const int v = it * 64 + lane;
             const int rr = v / VPR, cv = v % VPR;
-            const int y = yb + (rr >> 4), x = x0 + (rr & 15);
+            const int y = yb + (rr >> 4), x = x0 + sub_px<MODE>(rr);
             const int n = nw0 + cv * VEC;
             if (y < p.H && x < p.W && n < p.N) {
                 const float* src = tile + rr * TN + cv * VEC;
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     int hbase[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int py = 2 * (wm * MT + i) + (r >> 4), px = r & 15;
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = sub_px<MODE>(r);
         if (MODE == HIPSEG_CONV2S2)
             hbase[i] = (2 * py) * HW + 2 * px;
         else
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
-    conv_epilogue<T, MODE, BN>(p, acc, smem, mtile, img, y0, x0, n0);
+    conv_epilogue<T, MODE, BN, 4>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -386,17 +407,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
 // Needs 16-byte aligned channel vectors (C0 % 8 == 0, C1 % 8 == 0).
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
+template <int BN>
+struct DmaWaves {
+    static constexpr int value = BN == 128 ? 8 : 4;
+};
+// LDS ring depth: 3 buffers (chunk k+2 streams in while chunk k computes: a full chunk of MFMA time, ~1 us,
+// is not always enough to cover an L2/HBM round trip) where one workgroup per CU owns the LDS anyway.
+template <int BN>
+struct DmaBufs {
+    static constexpr int value = BN == 128 ? 3 : 2;
+};
+
 template <int MODE, int BN>
-__global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
+    constexpr int NW = DmaWaves<BN>::value, NBUF = DmaBufs<BN>::value, DIST = NBUF - 1;
     typedef bf16 T;
     constexpr int KC = 16, KG = 2;
     constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
     constexpr int NPIXP = (NPIX + 63) / 64 * 64;
-    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
-    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int WN = WG<BN, NW>::WN, WM = WG<BN, NW>::WM;
+    constexpr int MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
+    (void)WM;
     constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
-    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;  // 1-KiB DMA pieces per chunk
-    constexpr int NAW = (NA + 3) / 4, NBW = (NB + 3) / 4;    // per wave
+    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;            // 1-KiB DMA pieces per chunk
+    constexpr int NAW = (NA + NW - 1) / NW, NBW = (NB + NW - 1) / NW;  // per wave
     constexpr int RUNB = BN * 16;                            // bytes of one (tap, k-octet) weight run
     static_assert(B_BYTES % 1024 == 0 && A_BYTES % 1024 == 0, "whole DMA pieces");
     typedef __attribute__((address_space(3))) void lds_void;
@@ -438,7 +472,7 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
     int aoct[NAW];
 #pragma unroll
     for (int j = 0; j < NAW; ++j) {
-        const int s = j * 4 + wave;
+        const int s = j * NW + wave;
         aoct[j] = s / (NPIXP / 64);
         const int pix = (s % (NPIXP / 64)) * 64 + lane;
         const int iy = oy + pix / HW, ix = ox + pix % HW;
@@ -447,31 +481,34 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
     }
     const int kgp = p.Kp / 8;
 
-    auto stage = [&](int buf, int c0) {
+    // one 1-KiB DMA piece of chunk c0 into ring buffer `buf`; idx < NAW: this wave's idx-th A piece,
+    // otherwise its (idx - NAW)-th B piece.  Issued one at a time BETWEEN MFMA groups (an LDS-DMA holds the
+    // wave's issue port for ~100 cycles; issued in a burst after the barrier they idle the matrix pipe).
+    auto issue_piece = [&](int buf, int c0, int idx) {
         unsigned char* base = smem + buf * BUF;
-#pragma unroll
-        for (int j = 0; j < NAW; ++j) {
-            const int s = j * 4 + wave;
-            if (s < NA) {
-                const int c = c0 + aoct[j] * 8;
-                const T* src = zero;
-                if (apix[j] >= 0 && c < p.K) src = (c < p.C0) ? in0 + apix[j] * p.C0 + c : in1 + apix[j] * p.C1 + (c - p.C0);
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + s * 1024), 16, 0, 0);
-            }
-        }
-        const int kg0 = c0 / 8;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            const int s = j * 4 + wave;
-            if (s < NB) {
-                const int b = s * 1024 + lane * 16;
-                const int run = b / RUNB, off = b % RUNB;
-                const int tap = run / KG, kgl = run % KG;
-                const unsigned char* src = wp + (((size_t)tap * kgp + kg0 + kgl) * p.Np + n0) * 16 + off;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + s * 1024), 16, 0, 0);
-            }
+        unsigned char* dummy = smem + NBUF * BUF;  // 1-KiB sink for the pad pieces of waves with fewer real ones
+        if (idx < NAW) {
+            const int s = idx * NW + wave;
+            const bool real = s < NA && !(p.debug & 1);
+            const int c = c0 + aoct[idx] * 8;
+            const T* src = zero;
+            if (real && apix[idx] >= 0 && c < p.K)
+                src = (c < p.C0) ? in0 + apix[idx] * p.C0 + c : in1 + apix[idx] * p.C1 + (c - p.C0);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + s * 1024 : dummy), 16, 0, 0);
+        } else {
+            const int s = (idx - NAW) * NW + wave;
+            const bool real = s < NB && !(p.debug & 2);
+            const int b = s * 1024 + lane * 16;
+            const int run = b / RUNB, off = b % RUNB;
+            const int tap = run / KG, kgl = run % KG;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(zero);
+            if (real) src = wp + (((size_t)tap * kgp + c0 / 8 + kgl) * p.Np + n0) * 16 + off;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + A_BYTES + s * 1024 : dummy), 16, 0,
+                                             0);
         }
     };
+    constexpr int NPCW = NAW + NBW;                 // pieces per wave per chunk
+    constexpr int PPT = (NPCW + NT - 1) / NT;       // pieces issued per tap
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -483,7 +520,7 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
     int hbase[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int py = 2 * (wm * MT + i) + (r >> 4), px = r & 15;
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = sub_px<MODE>(r);
         hbase[i] = MODE == HIPSEG_CONV2S2 ? (2 * py) * HW + 2 * px : py * HW + px;
     }
     int ncol[NTL];
@@ -491,13 +528,28 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
     for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
 
     const int nchunks = p.Kp / KC;
-    stage(0, 0);
+    // prologue: the first DIST chunks go out at once
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nchunks) {
+#pragma unroll
+            for (int q = 0; q < NPCW; ++q) issue_piece(d, d * KC, q);
+        }
+    int cur = 0;  // ring slot of chunk kc
     for (int kc = 0; kc < nchunks; ++kc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk kc have landed
-        __syncthreads();  // ... everyone's have, and everyone is done reading the other buffer
-        if (kc + 1 < nchunks) stage((kc + 1) & 1, (kc + 1) * KC);
-        const unsigned char* sA = smem + (kc & 1) * BUF;
+        // every wave issues exactly NPCW pieces per chunk, so "chunk kc has landed" is a COUNTED wait that
+        // leaves the younger chunks' pieces in flight across the barrier (raw s_barrier: no vmcnt(0) drain)
+        if (kc + DIST - 1 < nchunks)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NPCW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone left the slot chunk kc+DIST will fill
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kc + DIST < nchunks;
+        const int nbuf = (cur + DIST) % NBUF, nc0 = (kc + DIST) * KC;
+        const unsigned char* sA = smem + cur * BUF;
         const unsigned char* sB = sA + A_BYTES;
+        cur = (cur + 1) % NBUF;
         // fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue (register double buffer):
         // with one wave per SIMD nothing else hides the ds_read latency
         bf16x8 bf[2][NTL], af[2][MT];
@@ -510,6 +562,13 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
             for (int i = 0; i < MT; ++i)
                 af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)h * NPIXP + hbase[i] + toff) * 16);
         };
+        if (p.debug & 4) {
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NPCW; ++q) issue_piece(nbuf, nc0, q);
+            }
+            continue;
+        }
         fetch(0, 0);
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
@@ -523,6 +582,10 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < NT) fetch((tap + 1) & 1, tap + 1);
+            if (more) {
+#pragma unroll
+                for (int q = tap * PPT; q < (tap + 1) * PPT && q < NPCW; ++q) issue_piece(nbuf, nc0, q);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = HALF; i < MT; ++i)
@@ -533,14 +596,15 @@ __global__ __launch_bounds__(256, (BN == 128 ? 1 : 2)) void conv_igemm_dma_kerne
         }
     }
 
-    conv_epilogue<bf16, MODE, BN>(p, acc, smem, mtile, img, y0, x0, n0);
+    if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 template <int MODE, int BN>
 int launch_dma(const ConvArgs& a, hipStream_t s) {
     constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t ring = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16);
-    constexpr size_t scratch = (size_t)4 * 32 * (BN / (BN >= 64 ? 2 : 1)) * sizeof(float);  // epilogue transpose tiles
+    constexpr size_t ring = DmaBufs<BN>::value * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 1024;
+    constexpr int NW = DmaWaves<BN>::value;
+    constexpr size_t scratch = (size_t)NW * 32 * (BN / WG<BN, NW>::WN) * sizeof(float);  // epilogue transpose tiles
     constexpr size_t lds = ring > scratch ? ring : scratch;
     static bool attr_set = false;
     if (!attr_set) {
@@ -549,7 +613,7 @@ int launch_dma(const ConvArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm_dma");
     return HIPSEG_OK;
 }
@@ -601,7 +665,11 @@ int launch_mode(const ConvArgs& a, int mode, int bn, hipStream_t s) {
     }
 }
 
-int bn_for(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
+int bn_for(int N) {
+    static const int bn_max = getenv("HIPSEG_BN_MAX") ? atoi(getenv("HIPSEG_BN_MAX")) : 128;  // tuning experiments
+    const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    return bn > bn_max ? bn_max : bn;
+}
 
 }  // namespace
 
@@ -652,6 +720,8 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     a.ntn = a.Np / bn;
     const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
     a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
+    static const int dbg = getenv("HIPSEG_IGEMM_DEBUG") ? atoi(getenv("HIPSEG_IGEMM_DEBUG")) : 0;
+    a.debug = dbg;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single conv layers through the C ABI (HIP-event timing).
+usage: micro_conv.py [igemm|wgrad] ; env HIPSEG_IGEMM_DEBUG for ablations"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-segmentation_amd")]
+import torch
+import hipseg
+from hipseg import _lib as L, ops
+
+LAYERS = [  # name, B, Cin, Cout, H
+    ("enc1.c1", 16, 64, 64, 256), ("enc2.c0", 16, 64, 128, 128), ("enc2.c1", 16, 128, 128, 128),
+    ("enc3.c1", 16, 256, 256, 64), ("bott.c1", 16, 512, 512, 32), ("dec4.c1", 16, 32, 32, 256),
+]
+which = sys.argv[1] if len(sys.argv) > 1 else "igemm"
+dt, td = L.BF16, torch.bfloat16
+for name, B, ci, co, H in LAYERS:
+    x = ops.nhwc_empty(B, ci, H, H, td, "cuda").normal_()
+    dy = ops.nhwc_empty(B, co, H, H, td, "cuda").normal_()
+    w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+    wp = ops._pack_conv(w, dt, False)
+    out = ops.nhwc_empty(B, co, H, H, td, "cuda")
+    stats = torch.empty(L.conv_mtiles(B, H, H) * 2 * co, device="cuda")
+    dw = torch.empty_like(w)
+    if which == "igemm":
+        fn = lambda: ops.igemm(dt, L.CONV3, x, ci, None, 0, wp, None, out, co, None, 0, stats, B, H, H)
+    else:
+        fn = lambda: ops._wgrad(dt, L.CONV3, x, None, dy, dw, B, H, H)
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    fl = 2.0 * B * H * H * ci * co * 9
+    print(f"{which} {name:8s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TF/s  dbg={os.environ.get('HIPSEG_IGEMM_DEBUG','0')}")
