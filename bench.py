@@ -101,24 +101,35 @@ def main():
 
     torch.manual_seed(0)
     model = getattr(un, args.model)().to(dev).train()
-    net = HipDDP(model) if world > 1 else model
+    use_graph = args.loop == "graph"
+    net = HipDDP(model, overlap=not use_graph) if world > 1 else model
     crit = HybridLoss()
-    use_graph = args.loop == "graph" and world == 1
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=use_graph)
     scaler = torch.amp.GradScaler("cuda")
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
     t = torch.randint(0, 3, (args.batch, args.size, args.size), generator=g).to(dev)
 
-    def step():
-        # loop body of the reference's TrainingWrapper.train (models/model_wrappers.py:167-177)
-        opt.zero_grad(set_to_none=not use_graph)
+    # loop body of the reference's TrainingWrapper.train (models/model_wrappers.py:167-177), in two halves
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda"):
-            out = net(x)
+            out = (model if use_graph else net)(x)  # graph mode: buffer broadcast is issued outside the graph
             loss = crit(out, t)
         scaler.scale(loss).backward()
+        if world > 1 and use_graph:
+            net.pack_gradients()
+        return loss
+
+    def opt_step():
         scaler.step(opt)
         scaler.update()
+
+    def step():
+        loss = fwd_bwd()
+        if world > 1 and use_graph:
+            net.allreduce_packed()
+        opt_step()
         return loss
 
     def barrier():
@@ -128,23 +139,42 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
-    graph = None
     if use_graph:
+        # eager warm-up on a side stream (allocator, lazy kernel attributes, RCCL communicators), then capture:
+        # N = 1: one hipGraph for the whole step.  N > 1: graph A = zero_grad + fwd + loss + scaled bwd + gradient
+        # pack, eager RCCL all-reduce of the flat buckets (and the DDP buffer broadcast), graph B = GradScaler +
+        # Adam reading the reduced bucket views.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
+                if world > 1:
+                    net.broadcast_buffers_now()
                 loss = step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=False)
-        with torch.cuda.graph(graph):
-            static_loss = step()
+        if world == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
 
-        def run():
-            graph.replay()
-            return static_loss
+            def run():
+                graph.replay()
+                return static_loss
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                static_loss = fwd_bwd()
+            net.use_bucket_grads()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                opt_step()
+
+            def run():
+                net.broadcast_buffers_now()
+                ga.replay()
+                net.allreduce_packed()
+                gb.replay()
+                return static_loss
     else:
         run = step
 
@@ -173,7 +203,9 @@ def main():
                                f"{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch {args.batch}/GPU, "
                                f"BASELINE.json configs[1]",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}", "loop": "hipgraph" if use_graph else "eager",
+                   "parallelism": f"dp{world}",
+                   "loop": ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager RCCL all-reduce + hipgraph(optimizer)")
+                   if use_graph else "eager (all-reduce overlapped with backward)",
                    "weights": "random init (nn default)", "final_loss": round(final_loss, 5)},
         "step_fraction_of_mfma_bound": round((TRAIN_GFLOP_PER_IMG * args.batch / 1e3 / PEAK_BF16_TFLOPS) / (ms / 1e3), 4)
         if args.model == "UNet" and args.size == 256 else None,

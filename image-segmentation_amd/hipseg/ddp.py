@@ -36,7 +36,12 @@ class _Bucket:
 
 
 class HipDDP(nn.Module):
-    def __init__(self, module, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0, broadcast_buffers=True):
+    def __init__(self, module, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0, broadcast_buffers=True,
+                 overlap=True):
+        """overlap=True : reduce each bucket from autograd hooks during backward (side stream, eager loops).
+        overlap=False: no hooks; the caller runs pack_gradients() / allreduce_packed() after backward --
+                       the form a hipGraph-captured step uses (fwd+bwd+pack in one graph, the collective
+                       eager between graphs, the optimiser in a second graph)."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
@@ -86,8 +91,11 @@ class HipDDP(nn.Module):
             for b in module.buffers():
                 if not b.is_floating_point():
                     dist.broadcast(b, 0, group=self.pg)
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._hook)
+        self.overlap = overlap
+        self._params = params
+        if overlap:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._hook)
 
     # ------------------------------------------------------------------ helpers
     def _bcast(self, tensors):
@@ -156,9 +164,41 @@ class HipDDP(nn.Module):
             b.pending = len(b.params)
         self._cb_queued = False
 
+    # ------------------------------------------------------------------ explicit (non-overlapped) reduction
+    def pack_gradients(self):
+        """copy every .grad into its flat bucket slot (multi-tensor copy: a few launches, capturable)."""
+        views = [v for b in self.buckets for v in b.views]
+        grads = [p.grad for b in self.buckets for p in b.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("pack_gradients: a parameter has no gradient")
+        torch._foreach_copy_(views, grads)
+
+    def allreduce_packed(self):
+        """average the flat buckets over ranks on the current stream and point .grad at the reduced views."""
+        if self.world > 1:
+            for b in self.buckets:
+                if self.on_gpu:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+                else:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
+                    b.flat.div_(self.world)
+        self.use_bucket_grads()
+
+    def use_bucket_grads(self):
+        for b in self.buckets:
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+
+    def reduce_gradients(self):
+        self.pack_gradients()
+        self.allreduce_packed()
+
+    def broadcast_buffers_now(self):
+        if self.broadcast_buffers and self.world > 1 and self._flat_buffers is not None:
+            dist.broadcast(self._flat_buffers, 0, group=self.pg)
+
     # ------------------------------------------------------------------ forward side
     def forward(self, *args, **kwargs):
-        if self.broadcast_buffers and self.world > 1 and self.module.training and torch.is_grad_enabled():
-            if self._flat_buffers is not None:
-                dist.broadcast(self._flat_buffers, 0, group=self.pg)
+        if self.module.training and torch.is_grad_enabled():
+            self.broadcast_buffers_now()
         return self.module(*args, **kwargs)

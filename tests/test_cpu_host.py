@@ -177,6 +177,17 @@ rm = net[1].running_mean.clone(); rm0 = rm.clone(); dist.broadcast(rm0, 0)
 assert net[1].running_mean.data_ptr() >= ddp._flat_buffers.data_ptr()
 with ddp.no_sync():
     ddp.zero_grad(); ddp(xs[rank]).sum().backward()
+# explicit (non-overlapped) reduction, the form the hipGraph-captured bench step uses
+net3 = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1))
+ddp3 = HipDDP(net3, overlap=False, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+ddp3.zero_grad(set_to_none=True)
+ddp3(xs[rank]).square().mean().backward()
+local = [p.grad.detach().clone() for p in net3.parameters()]
+ddp3.reduce_gradients()
+for p, g in zip(net3.parameters(), local):
+    ref = g.clone(); dist.all_reduce(ref); ref /= world
+    assert torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-8)
+    assert any(p.grad.data_ptr() == v.data_ptr() for b in ddp3.buckets for v in b.views)
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 """
