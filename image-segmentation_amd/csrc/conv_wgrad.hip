@@ -47,7 +47,27 @@ struct WgArgs {
     int ps, pa, pb;  // P pixel = (ps*y + pa, ps*x + pb)   (NT == 1 modes)
     int tiles_x, tiles_y, ntiles, S, UT, VT;
     int vec_ok_p, vec_ok_q;
+    // ConvTranspose2d weight gradient as ONE GEMM: P "pixel" (y,x) gathers its 4*Cout channels from the two
+    // dY rows 2y, 2y+1 (each row holds (b, co) = 2*Cout contiguous values at column 2x).  0 = plain tensor.
+    int convt_cout;
 };
+
+// element offset of channel c (first of an aligned 8/4-vector) of P pixel (img, gy, gx)
+__device__ __forceinline__ long p_offset(const WgArgs& a, int img, int gy, int gx, int c, const void*& base) {
+    if (a.convt_cout) {
+        const int two = 2 * a.convt_cout;
+        const int ra = c / two, rem = c - ra * two;
+        base = a.p0;
+        return (((long)img * a.PH + 2 * gy + ra) * a.PW + 2 * gx) * a.convt_cout + rem;
+    }
+    const long pixoff = ((long)img * a.PH + a.ps * gy + a.pa) * a.PW + a.ps * gx + a.pb;
+    if (c < a.CU0) {
+        base = a.p0;
+        return pixoff * a.CU0 + c;
+    }
+    base = a.p1;
+    return pixoff * a.CU1 + (c - a.CU0);
+}
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
@@ -96,22 +116,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
                 const int pix = cell / CVP, cv = cell % CVP;
                 const int hy = pix / PHW, hx = pix % PHW;
                 const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;  // Q-grid coordinates
-                const int iy = a.ps * gy + a.pa, ix = a.ps * gx + a.pb;
                 const int c = u0 + cv * VEC;
                 vec_t v;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.CU) {
-                    const long pixoff = ((long)img * a.PH + iy) * a.PW + ix;
                     if (a.vec_ok_p) {
-                        const T* src = (c < a.CU0) ? p0 + pixoff * a.CU0 + c : p1 + pixoff * a.CU1 + (c - a.CU0);
-                        v = *reinterpret_cast<const vec_t*>(src);
+                        const void* base;
+                        const long off = p_offset(a, img, gy, gx, c, base);
+                        v = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(base) + off);
                     } else {
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) {
                             const int cc = c + e;
-                            if (cc < a.CU)
-                                v[e] = (cc < a.CU0) ? p0[pixoff * a.CU0 + cc] : p1[pixoff * a.CU1 + (cc - a.CU0)];
+                            if (cc < a.CU) {
+                                const void* base;
+                                const long off = p_offset(a, img, gy, gx, cc, base);
+                                v[e] = reinterpret_cast<const T*>(base)[off];
+                            }
                         }
                     }
                 }
@@ -270,8 +292,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
                 const int c = u0 + lch[j];
                 const T* src = zero;
                 if (pix < NPP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.CU) {
-                    const long pixoff = ((long)img * a.PH + a.ps * gy + a.pa) * a.PW + a.ps * gx + a.pb;
-                    src = (c < a.CU0) ? p0 + pixoff * a.CU0 + c : p1 + pixoff * a.CU1 + (c - a.CU0);
+                    const void* base;
+                    const long off = p_offset(a, img, gy, gx, c, base);
+                    src = reinterpret_cast<const T*>(base) + off;
                 }
                 __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
             } else if (pc < NPC) {
@@ -383,8 +406,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
             o = ((size_t)v * CU + u) * 9 + t;  // (Cout=v, Cin=u, ky, kx)
         else if (mode == HIPSEG_CONV1)
             o = (size_t)v * CU + u;  // (Cout=v, Cin=u)
-        else
-            o = ((size_t)v * CU + u) * 4 + ab;  // ConvT (Cin=v, Cout=u, a, b)
+        else {  // ConvT: u = ab*Cout + co, CU = 4*Cout -> (Cin=v, Cout=co, a, b)
+            const int cout = CU / 4, tab = u / cout, co = u - tab * cout;
+            o = ((size_t)v * cout + co) * 4 + tab;
+        }
         dw[o] = sum;
     }
 }
@@ -465,6 +490,7 @@ int launch(const WgArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t hipseg_wgrad_workspace_elems(int mode, int CU, int CV, int B, int H, int W) {
+    if (mode == HIPSEG_CONVT) CU *= 4;  // one GEMM over the (a, b, co) = 4*Cout gathered channels
     size_t m = 0;
     for (int dt = 0; dt < 2; ++dt) {
         const Plan p = plan_for(dt, mode, CU, CV, B, H, W);
@@ -482,7 +508,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     HS_REQUIRE(p0 && q && dw && slabs && CU0 > 0 && CV > 0, "conv_wgrad: null operand or empty channel range");
     HS_REQUIRE((CU1 == 0) == (p1 == nullptr), "conv_wgrad: p1/CU1 mismatch");
     HS_REQUIRE(B > 0 && H > 0 && W > 0, "conv_wgrad: empty pixel grid");
-    const int CU = CU0 + CU1;
+    const int CU = mode == HIPSEG_CONVT ? 4 * CU0 : CU0 + CU1;
+    HS_REQUIRE(!(mode == HIPSEG_CONVT && CU1 != 0), "conv_wgrad: CONVT takes a single P tensor");
     const Plan pl = plan_for(dtype, mode, CU, CV, B, H, W);
     WgArgs a;
     a.p0 = p0;
@@ -512,13 +539,11 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
     a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
     a.vec_ok_q = (CV % vec == 0);
+    a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)pl.NT * CU * CV;
     const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    const int ntap_launch = mode == HIPSEG_CONVT ? 4 : 1;
-    for (int ab = 0; ab < ntap_launch; ++ab) {
-        a.pa = ab >> 1;
-        a.pb = ab & 1;
+    for (int ab = 0; ab < 1; ++ab) {
         int rc;
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;
         if (dtype == HIPSEG_BF16 && a.vec_ok_p && a.vec_ok_q && !no_dma)

@@ -37,6 +37,36 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
     }
 }
 
+// forward AND data-gradient operand of one Conv2d weight in a single launch (one launch per layer and step)
+template <typename T>
+__global__ void pack_conv_both_kernel(const float* __restrict__ w, T* __restrict__ wp, T* __restrict__ wpt, int Cout,
+                                      int Cin, int ks, int Kp0, int Np0, int Kp1, int Np1, int G, long total0,
+                                      long total1) {
+    const long total = total0 > total1 ? total0 : total1;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < total0) {  // K = Cin, N = Cout
+            const int g = (int)(idx % G);
+            const int n = (int)((idx / G) % Np0);
+            const int kg = (int)((idx / ((long)G * Np0)) % (Kp0 / G));
+            const int tap = (int)(idx / ((long)Kp0 * Np0));
+            const int k = kg * G + g, ky = tap / ks, kx = tap % ks;
+            float v = 0.f;
+            if (k < Cin && n < Cout) v = w[(((long)n * Cin + k) * ks + ky) * ks + kx];
+            wp[idx] = (T)v;
+        }
+        if (idx < total1) {  // K = Cout, N = Cin, taps flipped
+            const int g = (int)(idx % G);
+            const int n = (int)((idx / G) % Np1);
+            const int kg = (int)((idx / ((long)G * Np1)) % (Kp1 / G));
+            const int tap = (int)(idx / ((long)Kp1 * Np1));
+            const int k = kg * G + g, ky = tap / ks, kx = tap % ks;
+            float v = 0.f;
+            if (k < Cout && n < Cin) v = w[(((long)k * Cin + n) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+            wpt[idx] = (T)v;
+        }
+    }
+}
+
 // ConvTranspose2d weight (Cin, Cout, 2, 2)
 template <typename T>
 __global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int transpose,
@@ -82,6 +112,25 @@ extern "C" int hipseg_pack_conv_weight(const float* w, void* wp, int dtype, int 
         hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cout, Cin,
                            ksize, transpose, Kp, Np, G, total);
     HS_LAUNCH_CHECK("pack_conv_weight");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_pack_conv_weight_both(const float* w, void* wp, void* wpt, int dtype, int Cout, int Cin, int ksize,
+                                            hipseg_stream_t stream) {
+    HS_REQUIRE(w && wp && wpt && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pack_conv_weight_both: bad arguments");
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_conv_weight_both: bad dtype");
+    const int G = dtype == HIPSEG_BF16 ? 8 : 1;
+    const int Kp0 = hipseg_kpad(Cin, dtype), Np0 = hipseg_npad(Cout), Kp1 = hipseg_kpad(Cout, dtype), Np1 = hipseg_npad(Cin);
+    const long total0 = (long)ksize * ksize * Kp0 * Np0, total1 = (long)ksize * ksize * Kp1 * Np1;
+    const long total = total0 > total1 ? total0 : total1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(pack_conv_both_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16*)wp, (bf16*)wpt,
+                           Cout, Cin, ksize, Kp0, Np0, Kp1, Np1, G, total0, total1);
+    else
+        hipLaunchKernelGGL(pack_conv_both_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp,
+                           (float*)wpt, Cout, Cin, ksize, Kp0, Np0, Kp1, Np1, G, total0, total1);
+    HS_LAUNCH_CHECK("pack_conv_weight_both");
     return HIPSEG_OK;
 }
 

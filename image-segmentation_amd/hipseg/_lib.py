@@ -25,6 +25,7 @@ PROTOTYPES = {
     "hipseg_npad": (I, [I]),
     "hipseg_conv_mtiles": (I, [I, I, I]),
     "hipseg_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
+    "hipseg_pack_conv_weight_both": (I, [P, P, P, I, I, I, I, P]),
     "hipseg_pack_convT_weight": (I, [P, P, I, I, I, I, P]),
     "hipseg_conv_igemm": (I, [I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),

@@ -121,6 +121,16 @@ def _pack_conv(w, dt, transpose):
     return wp
 
 
+def _pack_conv_both(w, dt):
+    """forward and data-gradient operands of one conv weight, one launch."""
+    cout, cin, k, _ = w.shape
+    td = torch.bfloat16 if dt == L.BF16 else torch.float32
+    wp = torch.empty(k * k * L.kpad(cin, dt) * L.npad(cout), dtype=td, device=w.device)
+    wpt = torch.empty(k * k * L.kpad(cout, dt) * L.npad(cin), dtype=td, device=w.device)
+    L.pack_conv_weight_both(ptr(w), ptr(wp), ptr(wpt), dt, cout, cin, k, _stream())
+    return wp, wpt
+
+
 def _pack_convT(w, dt, transpose):
     cin, cout = w.shape[0], w.shape[1]
     if transpose:
@@ -152,15 +162,18 @@ class _BN:
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
 
 
-def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool):
+def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False):
     """conv3x3 (+bias, +BN batch statistics in the epilogue) -> BN finalize -> BN-apply+ReLU(+pool).
-    Returns (raw conv output, activated output, bn state)."""
+    Returns (raw conv output, activated output, bn state, data-gradient weight operand or None)."""
     B, _, H, W = x0.shape
     cout = w.shape[0]
     dev = x0.device
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
-    wp = _pack_conv(w, dt, False)
+    if need_t:
+        wp, wpt = _pack_conv_both(w, dt)
+    else:
+        wp, wpt = _pack_conv(w, dt, False), None
     raw = nhwc_empty(B, cout, H, W, x0.dtype, dev)
     bn = _BN(cout, dev)
     s = _stream()
@@ -177,10 +190,10 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool):
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     act = nhwc_empty(B, cout, Ho, Wo, x0.dtype, dev)
     L.bn_relu_apply(dt, ptr(raw), ptr(bn.scale), ptr(bn.shift), ptr(act), B, H, W, cout, int(pool), s)
-    return raw, act, bn
+    return raw, act, bn, wpt
 
 
-def _bn_relu_bwd(dt, dy, raw, bn, train, pool):
+def _bn_relu_bwd(dt, dy, raw, bn, train, pool, zero_bias=None):
     """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv)."""
     B, C, H, W = raw.shape
     dev = raw.device
@@ -197,7 +210,7 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool):
     if train:
         # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
         # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8)
-        dbias = torch.zeros(C, dtype=torch.float32, device=dev)
+        dbias = zero_bias if zero_bias is not None else torch.zeros(C, dtype=torch.float32, device=dev)
     else:
         dbias = _f32(C, dev)
         npix = B * H * W
@@ -214,29 +227,32 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool):
         dt = _dt(x0)
-        raw1, a1, bn1 = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False)
-        raw2, out, bn2 = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool)
-        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2)
+        grad = any(ctx.needs_input_grad)  # (grad mode itself is off inside Function.forward)
+        raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad)
+        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad)
+        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
         ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x0, x1, w1, w2, raw1, a1, raw2 = ctx.saved_tensors
+        x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors
         dt, train, pool = ctx.dt, ctx.train, ctx.pool
         B, C, H, W = raw2.shape
         dev = raw2.device
         s = _stream()
         dout = as_nhwc(dout, raw2.dtype)
         # ---- second conv layer
-        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool)
+        zb = torch.zeros(2 * C, dtype=torch.float32, device=dev) if train else None  # both conv-bias grads, one fill
+        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, zb[:C] if train else None)
         dw2 = torch.empty_like(w2)
         _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
-        wp2t = _pack_conv(w2, dt, True)
+        if wp2t is None:
+            wp2t = _pack_conv(w2, dt, True)
         da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
         igemm(dt, L.CONV3, draw2, C, None, 0, wp2t, None, da1, C, None, 0, None, B, H, W)
         # ---- first conv layer
-        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False)
+        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False, zb[C:] if train else None)
         dw1 = torch.empty_like(w1)
         _wgrad(dt, L.CONV3, x0, x1, draw1, dw1, B, H, W)
         dx0 = dx1 = None
@@ -245,7 +261,8 @@ class ConvBlockFn(torch.autograd.Function):
         if need0 or need1:
             c0 = x0.shape[1]
             c1 = x1.shape[1] if x1 is not None else 0
-            wp1t = _pack_conv(w1, dt, True)
+            if wp1t is None:
+                wp1t = _pack_conv(w1, dt, True)
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
             dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
             igemm(dt, L.CONV3, draw1, C, None, 0, wp1t, None, dx0, c0, dx1, c1, None, B, H, W)

@@ -61,6 +61,9 @@ int hipseg_conv_mtiles(int B, int H, int W);
  * (models/processing_blocks.py:43,46). */
 int hipseg_pack_conv_weight(const float* w, void* wp, int dtype, int Cout, int Cin, int ksize,
                             int transpose, hipseg_stream_t stream);
+/* both operands of one Conv2d weight (transpose=0 into wp, transpose=1 into wpt) in one launch */
+int hipseg_pack_conv_weight_both(const float* w, void* wp, void* wpt, int dtype, int Cout, int Cin,
+                                 int ksize, hipseg_stream_t stream);
 /* ConvTranspose2d weight (Cin,Cout,2,2) fp32.
  * transpose=0: forward operand  (HIPSEG_CONVT: 1 tap, K = Cin, N = 4*Cout, n = (a*2+b)*Cout+co)
  * transpose=1: data-gradient operand (HIPSEG_CONV2S2: 4 taps (a,b), K = Cout, N = Cin).
