@@ -164,7 +164,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
             const int rr = v / VPR, cv = v % VPR;
             const int y = yb + (rr >> 4), x = x0 + sub_px<MODE>(rr);
             const int n = nw0 + cv * VEC;
-            if (y < p.H && x < p.W && n < p.N) {
+            if (y < p.H && x < p.W && n < p.N && !(p.debug & 16)) {
                 const float* src = tile + rr * TN + cv * VEC;
                 if (vec_ok) {
                     typename VecOf<T>::type o;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (p.stats) {
+    if (p.stats && !(p.debug & 32)) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             ssum[j] += __shfl_xor(ssum[j], 32, 64);

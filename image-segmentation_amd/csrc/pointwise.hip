@@ -42,7 +42,36 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                                                         long HW, int Cout) {
     const int CG = Cout / V;
     const long total = (long)B * HW * CG;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (Cin <= MAXCIN && stride % CG == 0) {
+        // the channel group of a lane never changes along its grid-stride walk: keep its weights in registers
+        const int cg = (int)(i0 % CG);
+        float wr[MAXCIN][V], br[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            br[e] = b[cg * V + e];
+#pragma unroll
+            for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? w[(cg * V + e) * Cin + ci] : 0.f;
+        }
+        for (long i = i0; i < total; i += stride) {
+            const long p = i / CG;
+            const long n = p / HW, hw = p % HW;
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = br[e];
+#pragma unroll
+            for (int ci = 0; ci < MAXCIN; ++ci)
+                if (ci < Cin) {
+                    const float xv = x[(n * Cin + ci) * HW + hw];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = fmaf(wr[ci][e], xv, o[e]);
+                }
+            stv<T, V>(y + p * Cout + cg * V, o);
+        }
+        return;
+    }
+    for (long i = i0; i < total; i += stride) {
         const int cg = (int)(i % CG);
         const long p = i / CG;  // n*HW + pixel
         const long n = p / HW, hw = p % HW;
@@ -76,20 +105,33 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix) end = npix;
-        for (long p = start + pl; p < end; p += PL) {
-            const long n = p / HW, hw = p % HW;
-            float g[V];
-            ldv<T, V>(dy + p * Cout + cg * V, g);
+        constexpr int UNR = 4;  // pixels in flight per lane
+        for (long p0 = start + pl; p0 < end; p0 += (long)PL * UNR) {
+            float g[UNR][V], xv[UNR][MAXCIN];
 #pragma unroll
-            for (int ci = 0; ci < MAXCIN; ++ci) {
-                if (ci < Cin) {
-                    const float xv = x[(n * Cin + ci) * HW + hw];
+            for (int u = 0; u < UNR; ++u) {
+                const long p = p0 + (long)u * PL;
+                if (p < end) {
+                    const long n = p / HW, hw = p % HW;
+                    ldv<T, V>(dy + p * Cout + cg * V, g[u]);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) acc[ci][e] = fmaf(g[e], xv, acc[ci][e]);
+                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = ci < Cin ? x[(n * Cin + ci) * HW + hw] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g[u][e] = 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = 0.f;
                 }
             }
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[MAXCIN][e] += g[e];
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int ci = 0; ci < MAXCIN; ++ci)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[ci][e] = fmaf(g[u][e], xv[u][ci], acc[ci][e]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[MAXCIN][e] += g[u][e];
+            }
         }
     }
     const int R = 2048 / Cout;
@@ -195,24 +237,42 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix) end = npix;
-        for (long p = start + pl; p < end; p += PL) {
-            const long n = p / HW, hw = p % HW;
-            float xv[V], o[V];
-            ldv<T, V>(x + p * Cin + cg * V, xv);
+        constexpr int UNR = 2;  // pixels in flight per lane
+        for (long p0 = start + pl; p0 < end; p0 += (long)PL * UNR) {
+            float xv[UNR][V], g[UNR][MAXHC];
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = 0.f;
+            for (int u = 0; u < UNR; ++u) {
+                const long p = p0 + (long)u * PL;
+                if (p < end) {
+                    const long n = p / HW, hw = p % HW;
+                    ldv<T, V>(x + p * Cin + cg * V, xv[u]);
 #pragma unroll
-            for (int co = 0; co < MAXHC; ++co)
-                if (co < Cout) {
-                    const float g = dl[(n * Cout + co) * HW + hw];
-                    ab[co] += g;
+                    for (int co = 0; co < MAXHC; ++co) g[u][co] = co < Cout ? dl[(n * Cout + co) * HW + hw] : 0.f;
+                } else {
 #pragma unroll
-                    for (int e = 0; e < V; ++e) {
-                        o[e] = fmaf(g, wv[co][e], o[e]);
-                        aw[co][e] = fmaf(g, xv[e], aw[co][e]);
-                    }
+                    for (int e = 0; e < V; ++e) xv[u][e] = 0.f;
+#pragma unroll
+                    for (int co = 0; co < MAXHC; ++co) g[u][co] = 0.f;
                 }
-            stv<T, V>(dx + p * Cin + cg * V, o);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long p = p0 + (long)u * PL;
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+                for (int co = 0; co < MAXHC; ++co)
+                    if (co < Cout) {
+                        ab[co] += g[u][co];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            o[e] = fmaf(g[u][co], wv[co][e], o[e]);
+                            aw[co][e] = fmaf(g[u][co], xv[u][e], aw[co][e]);
+                        }
+                    }
+                if (p < end) stv<T, V>(dx + p * Cin + cg * V, o);
+            }
         }
     }
     const int R = 2048 / (Cin + 1);
