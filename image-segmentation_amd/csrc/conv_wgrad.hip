@@ -336,13 +336,26 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
             const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q0 * 64 + (chB ^ swz<T>(q0))));
             const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q1 * 64 + (chB ^ swz<T>(q1))));
             bfr[slot] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if constexpr (NT == 9) {
+                // the three kx taps of a halo row read pixel windows shifted by one: fetch 12 pixels once (3 reads
+                // of 4) and build the 3 fragments with in-register element shifts instead of 6 reads
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int ky = NT == 9 ? t / 3 : 0, kx = NT == 9 ? t % 3 : 0;
-                const int a0 = (y + ky) * PHW + kx0 + kx, a1 = a0 + 4;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int a0 = (y + ky) * PHW + kx0, a1 = a0 + 4, a2 = a0 + 8;
+                    const bf16x4 L = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
+                    const bf16x4 M = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
+                    const bf16x4 H = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a2 * 64 + (chA ^ swz<T>(a2))));
+                    const bf16x8 lm = __builtin_shufflevector(L, M, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 mh = __builtin_shufflevector(M, H, 0, 1, 2, 3, 4, 5, 6, 7);
+                    afr[slot][ky * 3 + 0] = lm;
+                    afr[slot][ky * 3 + 1] = __builtin_shufflevector(lm, mh, 1, 2, 3, 4, 5, 6, 7, 12);
+                    afr[slot][ky * 3 + 2] = __builtin_shufflevector(lm, mh, 2, 3, 4, 5, 6, 7, 12, 13);
+                }
+            } else {
+                const int a0 = y * PHW + kx0, a1 = a0 + 4;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
-                afr[slot][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                afr[slot][0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
         constexpr int FIRST = (NT + 1) / 2;
