@@ -7,6 +7,12 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
+# PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime instance this library binds to (same
+# process, same streams, same device context).  Importing torch first makes the loader resolve libhipseg's
+# libamdhip64 dependency to torch's already-loaded copy; loading ours first would create a second runtime
+# that does not see torch's device context ("no ROCm-capable device is detected" at the first launch).
+import torch  # noqa: F401  (must precede ctypes.CDLL below)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libhipseg.so")
 
