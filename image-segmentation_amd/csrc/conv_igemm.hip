@@ -123,7 +123,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
     __syncthreads();  // every wave is done with the staging buffers: LDS becomes the transpose scratch
     float* tile = reinterpret_cast<float*>(smem) + wave * (32 * TN);
 
-    float bv[NTL], ssum[NTL], ssq[NTL];
+    constexpr int GPW = MT / 2;  // 64-row statistics groups per wave (a 256-row tile has 4)
+    float bv[NTL], ssum[GPW][NTL], ssq[GPW][NTL];
     int ncol[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
@@ -132,8 +133,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
         int co = n;
         if (MODE == HIPSEG_CONVT) co = n % p.N0;
         bv[j] = (n < p.N && p.bias) ? p.bias[co] : 0.f;
-        ssum[j] = 0.f;
-        ssq[j] = 0.f;
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            ssum[g][j] = 0.f;
+            ssq[g][j] = 0.f;
+        }
     }
     // vector path needs every 8(4)-channel group to stay inside one destination tensor / tap group
     const bool vec_ok = (p.N0 % VEC == 0) && (p.N1 % VEC == 0);
@@ -151,8 +155,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
                 const float v = acc[i][j][e] + bv[j];
                 tile[rr * TN + j * 32 + r] = v;
                 if (nok && yb + (rr >> 4) < p.H && x0 + sub_px<MODE>(rr) < p.W) {
-                    ssum[j] += v;
-                    ssq[j] += v * v;
+                    ssum[i / 2][j] += v;
+                    ssq[i / 2][j] += v * v;
                 }
             }
         }
@@ -206,31 +210,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
         __builtin_amdgcn_wave_barrier();
     }
     if (p.stats && !(p.debug & 32)) {
+        // one statistics row per 64-row group (4 per tile): no cross-wave reduction, the finalize kernel sums rows
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 32, 64);
-            ssq[j] += __shfl_xor(ssq[j], 32, 64);
-        }
-        __syncthreads();  // transpose tiles are dead: reuse LDS for the cross-wave reduction
-        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
-        if (h == 0) {
+        for (int g = 0; g < GPW; ++g)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
-                red[(wm * 2 + 0) * BN + ncol[j]] = ssum[j];
-                red[(wm * 2 + 1) * BN + ncol[j]] = ssq[j];
+                const float S = ssum[g][j] + __shfl_xor(ssum[g][j], 32, 64);
+                const float Q = ssq[g][j] + __shfl_xor(ssq[g][j], 32, 64);
+                const int n = n0 + ncol[j];
+                if (h == 0 && n < p.N) {
+                    const size_t row = (size_t)mtile * 4 + wm * GPW + g;
+                    p.stats[(row * 2 + 0) * p.N + n] = S;
+                    p.stats[(row * 2 + 1) * p.N + n] = Q;
+                }
             }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-            float S = 0.f, Q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                S += red[(w * 2 + 0) * BN + tid];
-                Q += red[(w * 2 + 1) * BN + tid];
-            }
-            p.stats[((size_t)mtile * 2 + 0) * p.N + n0 + tid] = S;
-            p.stats[((size_t)mtile * 2 + 1) * p.N + n0 + tid] = Q;
-        }
     }
 }
 
@@ -599,6 +592,282 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
     if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Persistent form of the 256x128 bf16 kernel (one 512-thread workgroup per CU walks a strided list of
+// output tiles).  The (tile, K-chunk) sequence is ONE software pipeline: the LDS-DMA of the next tile's
+// first chunk is in flight while the last chunk of the current tile computes (no per-tile prologue bubble),
+// and a finished tile is PARKED as bf16 in a wave-private LDS region and drained to HBM with 16-byte stores
+// at the top of the next iteration, so its stores retire under the next tile's MFMAs instead of in an
+// exposed epilogue.  LDS: 2 x 48 KiB ring + 64 KiB park = the full 160 KiB of the CU.
+// Needs vector-aligned channels (C0, C1, N0, N1 multiples of 8).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int total_tiles) {
+    typedef bf16 T;
+    constexpr int BN = 128, NW = 8, KC = 16, KG = 2;
+    constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
+    constexpr int NPIXP = (NPIX + 63) / 64 * 64;
+    constexpr int WN = WG<BN, NW>::WN, MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
+    static_assert(MT == 2 && NTL == 2, "wave tile 64 rows x 64 channels");
+    constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
+    constexpr int NAW = (NA + NW - 1) / NW, NBW = (NB + NW - 1) / NW;
+    constexpr int RUNB = BN * 16;
+    constexpr int NPCW = NAW + NBW, PPT = (NPCW + NT - 1) / NT;
+    constexpr int PARKW = 64 * 64 * 2;  // bytes of one wave's parked 64x64 bf16 tile
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    unsigned char* park = smem + 2 * BUF + wave * PARKW;
+
+    const T* in0 = reinterpret_cast<const T*>(p.in0);
+    const T* in1 = reinterpret_cast<const T*>(p.in1);
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.wp);
+    const T* zero = reinterpret_cast<const T*>(&g_zero16);
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    const int kgp = p.Kp / 8;
+    const int nchunks = p.Kp / KC;
+    const int step = gridDim.x;
+
+    // ---- issue side state (runs one chunk ahead of the compute side)
+    int itile = blockIdx.x, ikc = 0, in0_ = 0;
+    long apix[NAW];
+    int aoct[NAW];
+    auto setup_issue = [&](int id) {
+        const int ntile = id % p.ntn, mtile = id / p.ntn;
+        const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
+        const int img = mtile / (p.tiles_x * p.tiles_y);
+        in0_ = ntile * BN;
+        int oy = ty * TH, ox = tx * TW;
+        if (MODE == HIPSEG_CONV3) {
+            oy -= 1;
+            ox -= 1;
+        } else if (MODE == HIPSEG_CONV2S2) {
+            oy *= 2;
+            ox *= 2;
+        }
+#pragma unroll
+        for (int j = 0; j < NAW; ++j) {
+            const int s = j * NW + wave;
+            aoct[j] = s / (NPIXP / 64);
+            const int pix = (s % (NPIXP / 64)) * 64 + lane;
+            const int iy = oy + pix / HW, ix = ox + pix % HW;
+            const bool ok = s < NA && pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            apix[j] = ok ? ((long)img * p.Hi + iy) * p.Wi + ix : -1;
+        }
+    };
+    auto issue_piece = [&](int buf, int idx) {
+        unsigned char* base = smem + buf * BUF;
+        const int c0 = ikc * KC;
+        if (idx < NAW) {
+            const int s = idx * NW + wave;
+            if (s < NA) {
+                const int c = c0 + aoct[idx] * 8;
+                const T* src = zero;
+                if (apix[idx] >= 0 && c < p.K)
+                    src = (c < p.C0) ? in0 + apix[idx] * p.C0 + c : in1 + apix[idx] * p.C1 + (c - p.C0);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + s * 1024), 16, 0, 0);
+            }
+        } else {
+            const int s = (idx - NAW) * NW + wave;
+            if (s < NB) {
+                const int b = s * 1024 + lane * 16;
+                const int run = b / RUNB, off = b % RUNB;
+                const int tap = run / KG, kgl = run % KG;
+                const unsigned char* src = wp + (((size_t)tap * kgp + c0 / 8 + kgl) * p.Np + in0_) * 16 + off;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + s * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto advance_issue = [&]() {
+        if (++ikc == nchunks) {
+            ikc = 0;
+            itile += step;
+            if (itile < total_tiles) setup_issue(itile);
+        }
+    };
+
+    // ---- compute side state
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int hbase[MT], ncol[NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = sub_px<MODE>(r);
+        hbase[i] = MODE == HIPSEG_CONV2S2 ? (2 * py) * HW + 2 * px : py * HW + px;
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
+
+    int ctile = blockIdx.x, kc = 0;
+    bool pending = false;
+    int d_img = 0, d_y0 = 0, d_x0 = 0, d_n0 = 0;  // coordinates of the parked tile
+
+    auto park_tile = [&]() {
+        const int ntile = ctile % p.ntn, mtile = ctile / p.ntn;
+        const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
+        d_img = mtile / (p.tiles_x * p.tiles_y);
+        d_y0 = ty * TH;
+        d_x0 = tx * TW;
+        d_n0 = ntile * BN;
+        bf16* pk = reinterpret_cast<bf16*>(park);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int n = d_n0 + ncol[j];
+            const bool nok = n < p.N;
+            int co = n;
+            if (MODE == HIPSEG_CONVT) co = n % p.N0;
+            const float bv = (nok && p.bias) ? p.bias[co] : 0.f;
+            float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int yb = d_y0 + 2 * (wm * MT + i);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[i][j][e] + bv;
+                    pk[(i * 32 + rr) * 64 + j * 32 + r] = (bf16)v;
+                    if (nok && yb + (rr >> 4) < p.H && d_x0 + sub_px<MODE>(rr) < p.W) {
+                        ssum += v;
+                        ssq += v * v;
+                    }
+                    acc[i][j][e] = 0.f;
+                }
+            }
+            if (p.stats) {
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                if (h == 0 && nok) {
+                    const size_t row = (size_t)mtile * 4 + wm;
+                    p.stats[(row * 2 + 0) * p.N + n] = ssum;
+                    p.stats[(row * 2 + 1) * p.N + n] = ssq;
+                }
+            }
+        }
+        pending = true;
+    };
+    auto drain_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int v = it * 64 + lane;
+            const int row = v >> 3, cv = v & 7;
+            const int i = row >> 5, rr = row & 31;
+            const int y = d_y0 + 2 * (wm * MT + i) + (rr >> 4), x = d_x0 + sub_px<MODE>(rr);
+            const int n = d_n0 + wn * (BN / WN) + cv * 8;
+            const uint4 val = *reinterpret_cast<const uint4*>(park + row * 128 + cv * 16);
+            if (y < p.H && x < p.W && n < p.N) {
+                T* dst;
+                if (MODE == HIPSEG_CONVT) {
+                    const int ab = n / p.N0, co = n - ab * p.N0;
+                    const long opix = ((long)d_img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+                    dst = out0 + opix * p.N0 + co;
+                } else {
+                    const long opix = ((long)d_img * p.H + y) * p.W + x;
+                    dst = (n < p.N0) ? out0 + opix * p.N0 + n : out1 + opix * p.N1 + (n - p.N0);
+                }
+                *reinterpret_cast<uint4*>(dst) = val;
+            }
+        }
+        pending = false;
+    };
+
+    const int my_tiles = (total_tiles - (int)blockIdx.x + step - 1) / step;
+    const int total_flat = my_tiles * nchunks;
+    setup_issue(itile);
+#pragma unroll
+    for (int q = 0; q < NPCW; ++q) issue_piece(0, q);
+    advance_issue();
+
+    for (int f = 0; f < total_flat; ++f) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk f landed (and the previous tile's drain retired)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (pending) drain_tile();
+        const bool more = f + 1 < total_flat;
+        const int nbuf = (f + 1) & 1;
+        const unsigned char* sA = smem + (f & 1) * BUF;
+        const unsigned char* sB = sA + A_BYTES;
+        bf16x8 bf[2][NTL], af[2][MT];
+        auto fetch = [&](int slot, int tap) {
+            const int toff = tap_off<MODE>(tap);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                bf[slot][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(tap * KG + h) * BN + ncol[j]) * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)h * NPIXP + hbase[i] + toff) * 16);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][0], bf[tap & 1][j], acc[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < NT) fetch((tap + 1) & 1, tap + 1);
+            if (more) {
+#pragma unroll
+                for (int q = tap * PPT; q < (tap + 1) * PPT && q < NPCW; ++q) issue_piece(nbuf, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][1], bf[tap & 1][j], acc[1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) advance_issue();
+        if (++kc == nchunks) {
+            park_tile();
+            kc = 0;
+            ctile += step;
+        }
+    }
+    if (pending) drain_tile();
+}
+
+template <int MODE>
+int launch_pers(const ConvArgs& a, hipStream_t s) {
+    constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
+    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * 128 * 16) + 8 * 64 * 64 * 2;
+    static_assert(lds <= 163840, "LDS budget");
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            hipseg_set_error("conv_igemm: cannot query the device");
+            return HIPSEG_EHIP;
+        }
+        ncu = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const long total = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    const int grid = (int)(total < ncu ? total : ncu);
+    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE>), dim3(grid), dim3(512), lds, s, a, (int)total);
+    HS_LAUNCH_CHECK("conv_igemm_pers");
+    return HIPSEG_OK;
+}
+
+int launch_pers_mode(const ConvArgs& a, int mode, hipStream_t s) {
+    switch (mode) {
+        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3>(a, s);
+        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1>(a, s);
+        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2>(a, s);
+        default: return launch_pers<HIPSEG_CONVT>(a, s);
+    }
+}
+
 template <int MODE, int BN>
 int launch_dma(const ConvArgs& a, hipStream_t s) {
     constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
@@ -681,7 +950,8 @@ extern "C" int hipseg_npad(int N) {
     const int bn = bn_for(N);
     return (N + bn - 1) / bn * bn;
 }
-extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return B * cdiv(H, TH) * cdiv(W, TW); }
+// rows of the statistics workspace: one per 64 output pixels (4 per 16x16 tile)
+extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return 4 * B * cdiv(H, TH) * cdiv(W, TW); }
 
 extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
                                  const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
@@ -725,6 +995,9 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
+        static const bool no_pers = getenv("HIPSEG_NO_PERSISTENT") != nullptr;
+        if (a.vec_ok && !no_dma && !no_pers && bn == 128 && N0 % 8 == 0 && N1 % 8 == 0)
+            return launch_pers_mode(a, mode, s);
         if (a.vec_ok && !no_dma) return launch_dma_mode(a, mode, bn, s);
         return launch_mode<bf16>(a, mode, bn, s);
     }

@@ -50,7 +50,7 @@ int hipseg_abi_version(void);
  * kernel's column tile.  Packed layout: [tap][Kp/G][Np][G], G = 8 (bf16) or 1 (f32).  */
 int hipseg_kpad(int K, int dtype);
 int hipseg_npad(int N);
-/* number of M tiles (= rows of the per-tile statistics workspace) for a (B,H,W) pixel grid */
+/* rows of the BatchNorm statistics workspace for a (B,H,W) pixel grid (one per 64 output pixels) */
 int hipseg_conv_mtiles(int B, int H, int W);
 
 /* Conv2d weight (Cout,Cin,kh,kw) fp32 -> packed [tap][Kp/G][Np][G] in `dtype`.
@@ -80,7 +80,7 @@ int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int Cin, int C
  *             NULL.  Used by the data-gradient of a dual-source conv.
  *   (H, W)  : the GEMM-M pixel grid = output grid for CONV3/CONV1/CONV2S2 (input grid is
  *             2H x 2W for CONV2S2), INPUT grid for CONVT (output is 2H x 2W, N0 = Cout).
- *   stats   : NULL or float[mtiles][2][N]: per-M-tile column sums and sums of squares of
+ *   stats   : NULL or float[hipseg_conv_mtiles()][2][N]: per-64-pixel column sums and sums of squares of
  *             the fp32 results (the BatchNorm batch-statistics partials, fused epilogue).
  * replaces: aten::conv2d 3x3/1x1 (processing_blocks.py:43,46), its dgrad, and
  *           aten::conv_transpose2d fwd/dgrad (processing_blocks.py:102,106). */

@@ -50,8 +50,8 @@ def test_host_geometry_functions(L):
     assert L.abi_version() == 1
     assert L.kpad(3, L.BF16) == 16 and L.kpad(32, L.BF16) == 32 and L.kpad(33, L.F32) == 40
     assert L.npad(32) == 32 and L.npad(64) == 64 and L.npad(65) == 128 and L.npad(512) == 512 and L.npad(3) == 32
-    assert L.conv_mtiles(16, 256, 256) == 16 * 16 * 16
-    assert L.conv_mtiles(1, 28, 28) == 4
+    assert L.conv_mtiles(16, 256, 256) == 4 * 16 * 16 * 16
+    assert L.conv_mtiles(1, 28, 28) == 16
     assert L.wgrad_workspace_elems(L.CONV3, 64, 64, 16, 256, 256) > 0
     assert L.loss_blocks(10) == 1 and L.loss_blocks(10 ** 9) == 1024
     assert L.bn_bwd_blocks(16, 256, 256, 64, L.BF16, 0) >= 1
