@@ -600,20 +600,21 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
 // at the top of the next iteration, so its stores retire under the next tile's MFMAs instead of in an
 // exposed epilogue.  LDS: 2 x 48 KiB ring + 64 KiB park = the full 160 KiB of the CU.
 // Needs vector-aligned channels (C0, C1, N0, N1 multiples of 8).
-template <int MODE>
+template <int MODE, int BN>
 __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int total_tiles) {
     typedef bf16 T;
-    constexpr int BN = 128, NW = 8, KC = 16, KG = 2;
+    constexpr int NW = 8, KC = 16, KG = 2;
     constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
     constexpr int NPIXP = (NPIX + 63) / 64 * 64;
     constexpr int WN = WG<BN, NW>::WN, MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
-    static_assert(MT == 2 && NTL == 2, "wave tile 64 rows x 64 channels");
+    static_assert(MT == 2 && (NTL == 1 || NTL == 2), "wave tile 64 rows x 32/64 channels");
+    constexpr int TN = 32 * NTL, VPR = TN / 8;  // channels / 16-byte vectors per row of the wave tile
     constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
     constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
     constexpr int NAW = (NA + NW - 1) / NW, NBW = (NB + NW - 1) / NW;
     constexpr int RUNB = BN * 16;
     constexpr int NPCW = NAW + NBW, PPT = (NPCW + NT - 1) / NT;
-    constexpr int PARKW = 64 * 64 * 2;  // bytes of one wave's parked 64x64 bf16 tile
+    constexpr int PARKW = 64 * TN * 2;  // bytes of one wave's parked 64 x TN bf16 tile
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[i][j][e] + bv;
-                    pk[(i * 32 + rr) * 64 + j * 32 + r] = (bf16)v;
+                    pk[(i * 32 + rr) * TN + j * 32 + r] = (bf16)v;
                     if (nok && yb + (rr >> 4) < p.H && d_x0 + sub_px<MODE>(rr) < p.W) {
                         ssum += v;
                         ssq += v * v;
@@ -758,13 +759,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
     };
     auto drain_tile = [&]() {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < VPR; ++it) {
             const int v = it * 64 + lane;
-            const int row = v >> 3, cv = v & 7;
+            const int row = v / VPR, cv = v % VPR;
             const int i = row >> 5, rr = row & 31;
             const int y = d_y0 + 2 * (wm * MT + i) + (rr >> 4), x = d_x0 + sub_px<MODE>(rr);
             const int n = d_n0 + wn * (BN / WN) + cv * 8;
-            const uint4 val = *reinterpret_cast<const uint4*>(park + row * 128 + cv * 16);
+            const uint4 val = *reinterpret_cast<const uint4*>(park + row * (TN * 2) + cv * 16);
             if (y < p.H && x < p.W && n < p.N) {
                 T* dst;
                 if (MODE == HIPSEG_CONVT) {
@@ -835,10 +836,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
     if (pending) drain_tile();
 }
 
-template <int MODE>
+template <int MODE, int BN>
 int launch_pers(const ConvArgs& a, hipStream_t s) {
     constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * 128 * 16) + 8 * 64 * 64 * 2;
+    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 8 * 64 * (BN / 2) * 2;
     static_assert(lds <= 163840, "LDS budget");
     static int ncu = 0;
     if (!ncu) {
@@ -849,22 +850,23 @@ int launch_pers(const ConvArgs& a, hipStream_t s) {
             return HIPSEG_EHIP;
         }
         ncu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long total = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     const int grid = (int)(total < ncu ? total : ncu);
-    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE>), dim3(grid), dim3(512), lds, s, a, (int)total);
+    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE, BN>), dim3(grid), dim3(512), lds, s, a, (int)total);
     HS_LAUNCH_CHECK("conv_igemm_pers");
     return HIPSEG_OK;
 }
 
+template <int BN>
 int launch_pers_mode(const ConvArgs& a, int mode, hipStream_t s) {
     switch (mode) {
-        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3>(a, s);
-        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1>(a, s);
-        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2>(a, s);
-        default: return launch_pers<HIPSEG_CONVT>(a, s);
+        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3, BN>(a, s);
+        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1, BN>(a, s);
+        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2, BN>(a, s);
+        default: return launch_pers<HIPSEG_CONVT, BN>(a, s);
     }
 }
 
@@ -996,8 +998,13 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
         static const bool no_pers = getenv("HIPSEG_NO_PERSISTENT") != nullptr;
-        if (a.vec_ok && !no_dma && !no_pers && bn == 128 && N0 % 8 == 0 && N1 % 8 == 0)
-            return launch_pers_mode(a, mode, s);
+        // persistent form for the 256x128 tile; the 64/32-wide tiles run two smaller workgroups per CU instead
+        // (measured faster than a persistent 8-wave 256x64 tile, which is kept for experiments)
+        static const bool pers64 = getenv("HIPSEG_PERSISTENT_BN64") != nullptr;
+        if (a.vec_ok && !no_dma && !no_pers && N0 % 8 == 0 && N1 % 8 == 0) {
+            if (bn == 128) return launch_pers_mode<128>(a, mode, s);
+            if (bn == 64 && pers64) return launch_pers_mode<64>(a, mode, s);
+        }
         if (a.vec_ok && !no_dma) return launch_dma_mode(a, mode, bn, s);
         return launch_mode<bf16>(a, mode, bn, s);
     }

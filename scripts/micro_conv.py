@@ -13,6 +13,10 @@ LAYERS = [  # name, B, Cin, Cout, H
     ("enc3.c1", 16, 256, 256, 64), ("bott.c1", 16, 512, 512, 32), ("dec4.c1", 16, 32, 32, 256),
 ]
 which = sys.argv[1] if len(sys.argv) > 1 else "igemm"
+only = os.environ.get("MICRO_LAYERS")
+if only:
+    LAYERS = [l for l in LAYERS if l[0] in only.split(",")]
+REPS = int(os.environ.get("MICRO_REPS", "20"))
 dt, td = L.BF16, torch.bfloat16
 for name, B, ci, co, H in LAYERS:
     x = ops.nhwc_empty(B, ci, H, H, td, "cuda").normal_()
@@ -29,7 +33,7 @@ for name, B, ci, co, H in LAYERS:
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = REPS
     e0.record()
     for _ in range(n):
         fn()
