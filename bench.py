@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet"])
+    ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet"])
     ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "graph"), choices=["eager", "graph"],
                     help="eager: Python launches every kernel each step; graph: the whole step is one hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,11 +100,19 @@ def main():
     from models.losses import HybridLoss
 
     torch.manual_seed(0)
-    model = getattr(un, args.model)().to(dev).train()
+    if args.model == "ClipUnet":
+        # BASELINE config 5: frozen CLIP ViT-B/32 image tower (random init: the pretrained weights are a network
+        # fetch) on PyTorch-ROCm + the HIP U-Net trunk
+        os.environ.setdefault("HIPSEG_CLIP_RANDOM_INIT", "1")
+        from models.CLIP_models import ClipUnet
+        model = ClipUnet().to(dev).train()
+    else:
+        model = getattr(un, args.model)().to(dev).train()
     use_graph = args.loop == "graph"
     net = HipDDP(model, overlap=not use_graph) if world > 1 else model
     crit = HybridLoss()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=use_graph)
+    opt = torch.optim.Adam([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=1e-4, fused=True,
+                           capturable=use_graph)
     scaler = torch.amp.GradScaler("cuda")
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
@@ -195,7 +203,8 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     out = {
-        "metric": "images/sec (whole node) U-Net 3x256x256 train step",
+        "metric": "images/sec (whole node) U-Net 3x256x256 train step" if (args.model, args.size) == ("UNet", 256)
+        else f"images/sec (whole node) {args.model} 3x{args.size}x{args.size} train step",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
