@@ -66,6 +66,9 @@ struct ConvArgs {
     int K, Kp, N, Np;
     int tiles_x, tiles_y, ntn;
     int vec_ok;
+    int stagger;  // initial s_sleep count (x ~3.5 us) of every second "generation" of workgroups: de-phases the two
+                  // workgroups that share a CU so one's epilogue stores overlap the other's MFMA phase
+    int ncu;
     int debug;  // ablation bits (HIPSEG_IGEMM_DEBUG): 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip epilogue
 };
 
@@ -73,7 +76,9 @@ struct ConvArgs {
 // one wave's LDS / barrier waits hide behind the other's MFMAs) on the 256x128 tile.
 template <int BN, int NW>
 struct WG {
-    static constexpr int WN = BN >= 64 ? 2 : 1, WM = NW / WN;
+    // one wave spans ALL channels of a <= 64-wide tile: its epilogue then writes whole 128-byte (64 ch) /
+    // 64-byte (32 ch) pixel rows instead of half rows, and a 64x64 wave tile needs 1.0 LDS reads per MFMA
+    static constexpr int WN = BN >= 128 ? 2 : 1, WM = NW / WN;
     static constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
 };
 
@@ -231,8 +236,8 @@ template <typename T, int MODE, int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int G = KT<T>::G, KC = KT<T>::KC, KG = KC / G;
     constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
-    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
-    constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    constexpr int WN = WG<BN, 4>::WN, WM = WG<BN, 4>::WM;
+    constexpr int MT = WG<BN, 4>::MT, NTL = WG<BN, 4>::NTL;
     constexpr int VEC = VecOf<T>::N;
     constexpr int CV = KC / VEC;
     typedef typename VecOf<T>::type vec_t;
@@ -521,6 +526,9 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
     for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
 
     const int nchunks = p.Kp / KC;
+    if (p.stagger && ((blockIdx.x / p.ncu) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // prologue: the first DIST chunks go out at once
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
@@ -600,13 +608,16 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
 // at the top of the next iteration, so its stores retire under the next tile's MFMAs instead of in an
 // exposed epilogue.  LDS: 2 x 48 KiB ring + 64 KiB park = the full 160 KiB of the CU.
 // Needs vector-aligned channels (C0, C1, N0, N1 multiples of 8).
-template <int MODE, int BN>
+// THT = tile rows: 16 (256x128 tile) or 32 (512-row "tall" tile for the <= 64-channel full-resolution layers: the
+// weight chunk is amortised over twice the pixels and every wave still owns a 64-row x 64/32-channel block).
+template <int MODE, int BN, int THT>
 __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int total_tiles) {
     typedef bf16 T;
     constexpr int NW = 8, KC = 16, KG = 2;
-    constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
+    constexpr int HW = Geo<MODE>::HW, NT = Geo<MODE>::NT;
+    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT), NPIX = HH * HW;
     constexpr int NPIXP = (NPIX + 63) / 64 * 64;
-    constexpr int WN = WG<BN, NW>::WN, MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
+    constexpr int WN = WG<BN, NW>::WN, WM = NW / WN, MT = (THT * TW / WM) / 32, NTL = WG<BN, NW>::NTL;
     static_assert(MT == 2 && (NTL == 1 || NTL == 2), "wave tile 64 rows x 32/64 channels");
     constexpr int TN = 32 * NTL, VPR = TN / 8;  // channels / 16-byte vectors per row of the wave tile
     constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
         const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
         const int img = mtile / (p.tiles_x * p.tiles_y);
         in0_ = ntile * BN;
-        int oy = ty * TH, ox = tx * TW;
+        int oy = ty * THT, ox = tx * TW;
         if (MODE == HIPSEG_CONV3) {
             oy -= 1;
             ox -= 1;
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
         const int ntile = ctile % p.ntn, mtile = ctile / p.ntn;
         const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
         d_img = mtile / (p.tiles_x * p.tiles_y);
-        d_y0 = ty * TH;
+        d_y0 = ty * THT;
         d_x0 = tx * TW;
         d_n0 = ntile * BN;
         bf16* pk = reinterpret_cast<bf16*>(park);
@@ -748,8 +759,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
             if (p.stats) {
                 ssum += __shfl_xor(ssum, 32, 64);
                 ssq += __shfl_xor(ssq, 32, 64);
-                if (h == 0 && nok) {
-                    const size_t row = (size_t)mtile * 4 + wm;
+                // statistics rows are per 64 output pixels of the 16-row tile grid (4 per 16x16 tile)
+                const int ty16 = ty * (THT / 16) + wm / 4, tiles_y16 = (p.H + 15) / 16;
+                if (h == 0 && nok && ty16 < tiles_y16) {
+                    const size_t row = (((size_t)d_img * tiles_y16 + ty16) * p.tiles_x + tx) * 4 + (wm & 3);
                     p.stats[(row * 2 + 0) * p.N + n] = ssum;
                     p.stats[(row * 2 + 1) * p.N + n] = ssq;
                 }
@@ -836,10 +849,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
     if (pending) drain_tile();
 }
 
-template <int MODE, int BN>
-int launch_pers(const ConvArgs& a, hipStream_t s) {
-    constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 8 * 64 * (BN / 2) * 2;
+template <int MODE, int BN, int THT>
+int launch_pers(const ConvArgs& a0, hipStream_t s) {
+    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT);
+    constexpr int NPIXP = (HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
+    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 8 * 64 * (BN / WG<BN, 8>::WN) * 2;
+    ConvArgs a = a0;
+    a.tiles_y = cdiv(a.H, THT);
     static_assert(lds <= 163840, "LDS budget");
     static int ncu = 0;
     if (!ncu) {
@@ -850,12 +866,12 @@ int launch_pers(const ConvArgs& a, hipStream_t s) {
             return HIPSEG_EHIP;
         }
         ncu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE, BN, THT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long total = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     const int grid = (int)(total < ncu ? total : ncu);
-    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE, BN>), dim3(grid), dim3(512), lds, s, a, (int)total);
+    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE, BN, THT>), dim3(grid), dim3(512), lds, s, a, (int)total);
     HS_LAUNCH_CHECK("conv_igemm_pers");
     return HIPSEG_OK;
 }
@@ -863,10 +879,10 @@ int launch_pers(const ConvArgs& a, hipStream_t s) {
 template <int BN>
 int launch_pers_mode(const ConvArgs& a, int mode, hipStream_t s) {
     switch (mode) {
-        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3, BN>(a, s);
-        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1, BN>(a, s);
-        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2, BN>(a, s);
-        default: return launch_pers<HIPSEG_CONVT, BN>(a, s);
+        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3, BN, 16>(a, s);
+        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1, BN, 16>(a, s);
+        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2, BN, 16>(a, s);
+        default: return launch_pers<HIPSEG_CONVT, BN, 16>(a, s);
     }
 }
 
@@ -910,7 +926,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     constexpr int KC = KT<T>::KC;
     constexpr int NPIX = Geo<MODE>::HH * Geo<MODE>::HW, NT = Geo<MODE>::NT;
     size_t lds = (size_t)(KC * NPIX + NT * KC * BN) * sizeof(T);
-    constexpr int WN = BN >= 64 ? 2 : 1;
+    constexpr int WN = WG<BN, 4>::WN;
     const size_t scratch = (size_t)4 * 32 * (BN / WN) * sizeof(float);  // per-wave fp32 transpose tiles (epilogue)
     if (lds < scratch) lds = scratch;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
@@ -994,16 +1010,24 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
     static const int dbg = getenv("HIPSEG_IGEMM_DEBUG") ? atoi(getenv("HIPSEG_IGEMM_DEBUG")) : 0;
     a.debug = dbg;
+    static const int stg = getenv("HIPSEG_STAGGER") ? atoi(getenv("HIPSEG_STAGGER")) : 0;
+    a.stagger = stg;
+    a.ncu = 256;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
-        static const bool no_pers = getenv("HIPSEG_NO_PERSISTENT") != nullptr;
+        // The persistent variants (cross-tile pipeline + parked stores, 512-row tall tiles) pass every parity
+        // test but measured 2-3 % SLOWER than the plain 3-deep-ring kernel on the full training step
+        // (same box, back to back), so they are opt-in: HIPSEG_PERSISTENT=1.
+        static const bool no_pers = getenv("HIPSEG_PERSISTENT") == nullptr;
         // persistent form for the 256x128 tile; the 64/32-wide tiles run two smaller workgroups per CU instead
-        // (measured faster than a persistent 8-wave 256x64 tile, which is kept for experiments)
-        static const bool pers64 = getenv("HIPSEG_PERSISTENT_BN64") != nullptr;
+        // (measured faster than a persistent 8-wave 256x64 tile)
         if (a.vec_ok && !no_dma && !no_pers && N0 % 8 == 0 && N1 % 8 == 0) {
             if (bn == 128) return launch_pers_mode<128>(a, mode, s);
-            if (bn == 64 && pers64) return launch_pers_mode<64>(a, mode, s);
+            // <= 64-channel 3x3 layers (full resolution in the U-Net): persistent 512-row tall tiles
+            static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
+            if (mode == HIPSEG_CONV3 && H >= 32 && !no_tall)
+                return bn == 64 ? launch_pers<HIPSEG_CONV3, 64, 32>(a, s) : launch_pers<HIPSEG_CONV3, 32, 32>(a, s);
         }
         if (a.vec_ok && !no_dma) return launch_dma_mode(a, mode, bn, s);
         return launch_mode<bf16>(a, mode, bn, s);

@@ -50,6 +50,7 @@ struct WgArgs {
     // ConvTranspose2d weight gradient as ONE GEMM: P "pixel" (y,x) gathers its 4*Cout channels from the two
     // dY rows 2y, 2y+1 (each row holds (b, co) = 2*Cout contiguous values at column 2x).  0 = plain tensor.
     int convt_cout;
+    int debug;  // ablation bits (HIPSEG_WGRAD_DEBUG): 1 skip P staging, 2 skip Q staging, 4 skip MFMA, 8 skip slab store
 };
 
 // element offset of channel c (first of an aligned 8/4-vector) of P pixel (img, gy, gx)
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             const int pc = j * 4 + wave;
-            if (pc < NPC_P) {
+            if (pc < NPC_P && !(a.debug & 1)) {
                 const int pix = lpix[j];
                 const int gy = y0 + pix / PHW - HALO, gx = x0 + pix % PHW - HALO;
                 const int c = u0 + lch[j];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
                     src = reinterpret_cast<const T*>(base) + off;
                 }
                 __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
-            } else if (pc < NPC) {
+            } else if (pc >= NPC_P && pc < NPC && !(a.debug & 2)) {
                 const int pix = lpix[j];
                 const int gy = y0 + pix / TW, gx = x0 + pix % TW;
                 const int c = v0 + lch[j];
@@ -359,6 +360,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
             }
         };
         constexpr int FIRST = (NT + 1) / 2;
+        if (a.debug & 4) {
+            buf ^= 1;
+            continue;
+        }
         fetch(0, 0);
 #pragma unroll
         for (int y = 0; y < TH; ++y) {
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
             const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
-            a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
+            if (!(a.debug & 8)) a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
         }
     }
 }
@@ -553,6 +558,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
     a.vec_ok_q = (CV % vec == 0);
     a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
+    static const int dbg = getenv("HIPSEG_WGRAD_DEBUG") ? atoi(getenv("HIPSEG_WGRAD_DEBUG")) : 0;
+    a.debug = dbg;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)pl.NT * CU * CV;
     const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
