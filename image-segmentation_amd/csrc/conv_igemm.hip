@@ -74,12 +74,12 @@ struct ConvArgs {
 
 // Wave grid of a workgroup.  The generic kernel runs 4 waves; the DMA kernel runs 8 waves (two per SIMD, so
 // one wave's LDS / barrier waits hide behind the other's MFMAs) on the 256x128 tile.
-template <int BN, int NW>
+template <int BN, int NW, int THT = 16>
 struct WG {
     // one wave spans ALL channels of a <= 64-wide tile: its epilogue then writes whole 128-byte (64 ch) /
     // 64-byte (32 ch) pixel rows instead of half rows, and a 64x64 wave tile needs 1.0 LDS reads per MFMA
     static constexpr int WN = BN >= 128 ? 2 : 1, WM = NW / WN;
-    static constexpr int MT = (BM / WM) / 32, NTL = (BN / WN) / 32;
+    static constexpr int MT = (THT * TW / WM) / 32, NTL = (BN / WN) / 32;
 };
 
 // M sub-tile (32 MFMA rows) -> tile pixels: rows 0-15 = 16 pixels of tile row 2s, rows 16-31 = tile row 2s+1
@@ -108,11 +108,14 @@ __device__ __forceinline__ constexpr int tap_off(int tap) {
 // instead turns its 32-pixel x (32*NTL)-channel sub-tile through a private LDS tile (fp32) and
 // writes full 16-byte channel vectors per lane: 128 contiguous bytes per pixel for a 64-channel wave tile.
 // Also adds the bias and reduces the BatchNorm partial statistics (sum, sum of squares per channel).
-template <typename T, int MODE, int BN, int NW>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[WG<BN, NW>::MT][WG<BN, NW>::NTL],
+template <typename T, int MODE, int BN, int NW, int THT = 16>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
+                                              f32x16 (&acc)[WG<BN, NW, THT>::MT][WG<BN, NW, THT>::NTL],
                                               unsigned char* smem, int mtile, int img, int y0, int x0, int n0) {
-    constexpr int WN = WG<BN, NW>::WN, WM = WG<BN, NW>::WM;
-    constexpr int MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
+    constexpr int WN = WG<BN, NW, THT>::WN, WM = WG<BN, NW, THT>::WM;
+    constexpr int MT = WG<BN, NW, THT>::MT, NTL = WG<BN, NW, THT>::NTL;
+    (void)WM;
+    (void)mtile;
     constexpr int TN = 32 * NTL;            // channels of the wave tile
     constexpr int VEC = VecOf<T>::N;        // channels per 16-byte store
     constexpr int VPR = TN / VEC;           // vectors per pixel row
@@ -223,8 +226,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[W
                 const float S = ssum[g][j] + __shfl_xor(ssum[g][j], 32, 64);
                 const float Q = ssq[g][j] + __shfl_xor(ssq[g][j], 32, 64);
                 const int n = n0 + ncol[j];
-                if (h == 0 && n < p.N) {
-                    const size_t row = (size_t)mtile * 4 + wm * GPW + g;
+                // statistics rows follow the 16-row tile grid (4 rows of 64 pixels per 16x16 tile)
+                const int G = wm * GPW + g, ty16 = y0 / 16 + G / 4, tiles_y16 = (p.H + 15) / 16;
+                if (h == 0 && n < p.N && ty16 < tiles_y16) {
+                    const size_t row = (((size_t)img * tiles_y16 + ty16) * p.tiles_x + x0 / 16) * 4 + (G & 3);
                     p.stats[(row * 2 + 0) * p.N + n] = S;
                     p.stats[(row * 2 + 1) * p.N + n] = Q;
                 }
@@ -405,26 +410,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
 // Needs 16-byte aligned channel vectors (C0 % 8 == 0, C1 % 8 == 0).
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int BN>
+template <int BN, int THT = 16>
 struct DmaWaves {
     static constexpr int value = BN == 128 ? 8 : 4;
 };
 // LDS ring depth: 3 buffers (chunk k+2 streams in while chunk k computes: a full chunk of MFMA time, ~1 us,
 // is not always enough to cover an L2/HBM round trip) where one workgroup per CU owns the LDS anyway.
-template <int BN>
+template <int BN, int THT = 16>
 struct DmaBufs {
-    static constexpr int value = BN == 128 ? 3 : 2;
+    static constexpr int value = (BN == 128 && THT == 16) ? 3 : 2;
 };
 
-template <int MODE, int BN>
-__global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
-    constexpr int NW = DmaWaves<BN>::value, NBUF = DmaBufs<BN>::value, DIST = NBUF - 1;
+// THT = tile rows: 16 (256-pixel tile) or 32 (512-pixel "tall" tile: every wave owns a 128-row x 64-channel block,
+// 0.75 LDS fragment reads per MFMA instead of 1.0, and the weight chunk is amortised over twice the pixels --
+// the main loop is LDS-bandwidth bound: fragment reads + DMA writes share the LDS port with nothing to spare).
+template <int MODE, int BN, int THT = 16>
+__global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm_dma_kernel(ConvArgs p) {
+    constexpr int NW = DmaWaves<BN, THT>::value, NBUF = DmaBufs<BN, THT>::value, DIST = NBUF - 1;
     typedef bf16 T;
     constexpr int KC = 16, KG = 2;
-    constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
+    constexpr int HW = Geo<MODE>::HW, NT = Geo<MODE>::NT;
+    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT), NPIX = HH * HW;
     constexpr int NPIXP = (NPIX + 63) / 64 * 64;
-    constexpr int WN = WG<BN, NW>::WN, WM = WG<BN, NW>::WM;
-    constexpr int MT = WG<BN, NW>::MT, NTL = WG<BN, NW>::NTL;
+    constexpr int WN = WG<BN, NW, THT>::WN, WM = WG<BN, NW, THT>::WM;
+    constexpr int MT = WG<BN, NW, THT>::MT, NTL = WG<BN, NW, THT>::NTL;
     (void)WM;
     constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
     constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;            // 1-KiB DMA pieces per chunk
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
     const int tx = mtile % p.tiles_x;
     const int ty = (mtile / p.tiles_x) % p.tiles_y;
     const int img = mtile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = ty * THT, x0 = tx * TW;
     const int n0 = ntile * BN;
     int oy, ox;
     if (MODE == HIPSEG_CONV3) {
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(64 * DmaWaves<BN>::value, (BN == 128 ? 2 : 2)) void
         }
     }
 
-    if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW>(p, acc, smem, mtile, img, y0, x0, n0);
+    if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -886,21 +895,25 @@ int launch_pers_mode(const ConvArgs& a, int mode, hipStream_t s) {
     }
 }
 
-template <int MODE, int BN>
-int launch_dma(const ConvArgs& a, hipStream_t s) {
-    constexpr int NPIXP = (Geo<MODE>::HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t ring = DmaBufs<BN>::value * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 1024;
-    constexpr int NW = DmaWaves<BN>::value;
-    constexpr size_t scratch = (size_t)NW * 32 * (BN / WG<BN, NW>::WN) * sizeof(float);  // epilogue transpose tiles
+template <int MODE, int BN, int THT = 16>
+int launch_dma(const ConvArgs& a0, hipStream_t s) {
+    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT);
+    constexpr int NPIXP = (HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
+    constexpr size_t ring = DmaBufs<BN, THT>::value * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 1024;
+    constexpr int NW = DmaWaves<BN, THT>::value;
+    constexpr size_t scratch = (size_t)NW * 32 * (BN / WG<BN, NW, THT>::WN) * sizeof(float);  // epilogue transposes
     constexpr size_t lds = ring > scratch ? ring : scratch;
+    static_assert(lds <= 163840, "LDS budget");
+    ConvArgs a = a0;
+    a.tiles_y = cdiv(a.H, THT);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN, THT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN, THT>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm_dma");
     return HIPSEG_OK;
 }
@@ -1029,7 +1042,16 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             if (mode == HIPSEG_CONV3 && H >= 32 && !no_tall)
                 return bn == 64 ? launch_pers<HIPSEG_CONV3, 64, 32>(a, s) : launch_pers<HIPSEG_CONV3, 32, 32>(a, s);
         }
-        if (a.vec_ok && !no_dma) return launch_dma_mode(a, mode, bn, s);
+        if (a.vec_ok && !no_dma) {
+            // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)
+            static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
+            const long tall_wgs = (long)a.B * a.tiles_x * cdiv(H, 32) * a.ntn;
+            if (mode == HIPSEG_CONV3 && !no_tall && H >= 32 && bn >= 64 && tall_wgs >= (bn == 128 ? 256 : 512)) {
+                if (bn == 128) return launch_dma<HIPSEG_CONV3, 128, 32>(a, s);
+                return launch_dma<HIPSEG_CONV3, 64, 32>(a, s);  // (32-wide tiles measured slower tall)
+            }
+            return launch_dma_mode(a, mode, bn, s);
+        }
         return launch_mode<bf16>(a, mode, bn, s);
     }
     return launch_mode<float>(a, mode, bn, s);
