@@ -31,8 +31,8 @@ __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
 // stats: [mtiles][2][C]; block = 16 channels x 16 tile slices, double accumulation.
 // stats: [mtiles][2][C].  One launch: block = 4 channels x 64 tile slices (each lane sums <= mtiles/64 rows,
 // all loads independent), double accumulation, LDS tree over the slices, then the per-channel finish.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int C,
-                                                           double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int rstride,
+                                                           int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* running_mean, float* running_var,
                                                            long long* nbt, float* mean, float* invstd, float* scale,
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (c < C) {
 #pragma unroll 4
         for (int t = sl; t < mtiles; t += 64) {
-            S += (double)stats[((size_t)t * 2 + 0) * C + c];
-            Q += (double)stats[((size_t)t * 2 + 1) * C + c];
+            S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
+            Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
         }
     }
     sS[sl][cl] = S;
@@ -472,9 +472,18 @@ extern "C" int hipseg_bn_finalize(float* stats, int mtiles, int C, double count,
     HS_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && C > 0 && mtiles > 0 && count > 0,
                "bn_finalize: bad arguments");
     HS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var mismatch");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats,
-                       mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var,
-                       reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale, shift);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rows = mtiles, rstride = 1;
+    if (mtiles > 2048) {  // full-resolution layers: wide in-place pre-reduction of 32-row chunks first
+        rstride = 32;
+        rows = cdiv(mtiles, rstride);
+        hipLaunchKernelGGL(colreduce_inplace_kernel, dim3(cdiv(2 * C, 64), rows), dim3(256), 0, s, stats, mtiles,
+                           (long)2 * C, rstride);
+        HS_LAUNCH_CHECK("bn_finalize_stage1");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, stats, rows, rstride, C, count, gamma, beta,
+                       eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), mean,
+                       invstd, scale, shift);
     HS_LAUNCH_CHECK("bn_finalize");
     return HIPSEG_OK;
 }
