@@ -240,15 +240,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
 __device__ uint4 g_wg_zero16 = {0u, 0u, 0u, 0u};
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
+struct DmaGeo {
+    static constexpr int TH = 16, KH = TH / 2;               // pixel rows per tile / per k-half
+    static constexpr int HALO = NT == 9 ? 1 : 0;
+    static constexpr int PHW = TW + 2 * HALO, NPP = (TH + 2 * HALO) * PHW, NPQ = TH * TW;
+    static constexpr int NW = 8;                             // waves: 2 (u) x 2 (v) x 2 (pixel halves)
+    static constexpr int NPC_P = (NPP + 7) / 8, NPC_Q = NPQ / 8;  // 1-KiB DMA pieces of the P / Q image
+    static constexpr int NPW_P = (NPC_P + NW - 1) / NW, NPW_Q = NPC_Q / NW, NPW = NPW_P + NPW_Q;  // per wave
+    static constexpr int PP_BYTES = NPC_P * 1024, Q_BYTES = NPQ * 128, BUF = PP_BYTES + Q_BYTES;
+    static constexpr int NR = KH + 2 * HALO;                 // halo rows a k-half walks
+    static constexpr int PPR = (NPW + NR - 1) / NR;          // DMA pieces issued per halo row
+    static constexpr size_t LDS = 2 * (size_t)BUF;
+};
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     typedef bf16 T;
-    constexpr int TH = 16, UC = 64, VC = 64, WV = 2;
-    constexpr int HALO = NT == 9 ? 1 : 0;
-    constexpr int PHW = TW + 2 * HALO, NPP = (TH + 2 * HALO) * PHW, NPQ = TH * TW;
-    constexpr int NPP8 = (NPP + 7) / 8 * 8;            // P image padded to whole 8-pixel DMA pieces
-    constexpr int PP_BYTES = NPP8 * 128, Q_BYTES = NPQ * 128, BUF = PP_BYTES + Q_BYTES;
-    constexpr int NPC_P = NPP8 / 8, NPC_Q = NPQ / 8, NPC = NPC_P + NPC_Q;
-    constexpr int NPW = (NPC + 3) / 4;                 // pieces per wave
+    typedef DmaGeo<NT> G;
+    constexpr int UC = 64, VC = 64, KH = G::KH, HALO = G::HALO, PHW = G::PHW, NPP = G::NPP;
+    constexpr int PP_BYTES = G::PP_BYTES, BUF = G::BUF, NPW_P = G::NPW_P, NPW = G::NPW, NR = G::NR, PPR = G::PPR;
+    constexpr int NW = G::NW, NPC_P = G::NPC_P;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -257,59 +268,78 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int wu = wave / WV, wv = wave % WV;
+    const int wu = wave & 1, wv = (wave >> 1) & 1, kh = wave >> 2;
     const int vt = blockIdx.x % a.VT;
     const int ut = (blockIdx.x / a.VT) % a.UT;
     const int s = blockIdx.x / (a.VT * a.UT);
     const int u0 = ut * UC, v0 = vt * VC;
-    const T* p0 = reinterpret_cast<const T*>(a.p0);
-    const T* p1 = reinterpret_cast<const T*>(a.p1);
-    const T* q = reinterpret_cast<const T*>(a.q);
-    const T* zero = reinterpret_cast<const T*>(&g_wg_zero16);
+    const char* zero = reinterpret_cast<const char*>(&g_wg_zero16);
 
-    // this lane's (pixel-in-image, source channel chunk) for each of its wave's pieces
+    // ---- staging addresses.  Everything that does not change from tile to tile is folded into per-lane constants
+    // (source base incl. channel, pixel stride, channel validity); a piece then costs ~a dozen VALU ops.
+    // A lane copies 16 B = 8 channels of pixel row `prow` of its wave's 8-pixel piece; the XOR swizzle of the
+    // image is applied to the SOURCE chunk and depends on bit 1 of the pixel index = bit 1 of prow only.
     const int prow = lane >> 3, pchunk = lane & 7;
-    int lpix[NPW], lch[NPW];
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        const int pc = j * 4 + wave;
-        const int pix = (pc < NPC_P ? pc : pc - NPC_P) * 8 + prow;  // pixel index inside the P or Q image
-        lpix[j] = pix;
-        lch[j] = (pchunk ^ (((pix >> 1) & 1) << 2)) * 8;  // swizzled source chunk -> first channel
+    const int lch = (pchunk ^ (((prow >> 1) & 1) << 2)) * 8;
+    const int cP = u0 + lch, cQ = v0 + lch;
+    const bool okcP = cP < a.CU && !(a.debug & 1), okcQ = cQ < a.CV && !(a.debug & 2);
+    const char* lbaseP;
+    int strideP;  // bytes between consecutive P "pixels"
+    int ps = a.ps, pa = a.pa;
+    if (a.convt_cout) {  // gather of (row parity, column parity, co) from the two dY rows 2y, 2y+1 (see p_offset)
+        const int two = 2 * a.convt_cout, ra = cP / two, rem = cP - ra * two;
+        lbaseP = reinterpret_cast<const char*>(a.p0) + ((long)ra * a.PW * a.convt_cout + rem) * 2;
+        strideP = a.convt_cout * 2;
+        ps = 2;
+        pa = 0;
+    } else if (cP < a.CU0) {
+        lbaseP = reinterpret_cast<const char*>(a.p0) + (long)cP * 2;
+        strideP = a.CU0 * 2;
+    } else {
+        lbaseP = reinterpret_cast<const char*>(a.p1) + (long)(cP - a.CU0) * 2;
+        strideP = a.CU1 * 2;
     }
+    const int pb = a.convt_cout ? 0 : a.pb;
+    const char* lbaseQ = reinterpret_cast<const char*>(a.q) + (long)cQ * 2;
+    const int strideQ = a.CV * 2;
 
-    auto stage = [&](int buf, int tile) {
-        const int tx = tile % a.tiles_x;
-        const int ty = (tile / a.tiles_x) % a.tiles_y;
-        const int img = tile / (a.tiles_x * a.tiles_y);
-        const int y0 = ty * TH, x0 = tx * TW;
-        unsigned char* base = smem + buf * BUF;
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) {
-            const int pc = j * 4 + wave;
-            if (pc < NPC_P && !(a.debug & 1)) {
-                const int pix = lpix[j];
-                const int gy = y0 + pix / PHW - HALO, gx = x0 + pix % PHW - HALO;
-                const int c = u0 + lch[j];
-                const T* src = zero;
-                if (pix < NPP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.CU) {
-                    const void* base;
-                    const long off = p_offset(a, img, gy, gx, c, base);
-                    src = reinterpret_cast<const T*>(base) + off;
-                }
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
-            } else if (pc >= NPC_P && pc < NPC && !(a.debug & 2)) {
-                const int pix = lpix[j];
-                const int gy = y0 + pix / TW, gx = x0 + pix % TW;
-                const int c = v0 + lch[j];
-                const T* src = zero;
-                if (gy < a.H && gx < a.W && c < a.CV) src = q + (((long)img * a.H + gy) * a.W + gx) * a.CV + c;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + PP_BYTES + (pc - NPC_P) * 1024), 16,
-                                                 0, 0);
+    // tile walk tile = s, s + S, ... as incremental (tx, ty, img) updates (no per-tile divisions)
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int sx = a.S % a.tiles_x, sy = (a.S / a.tiles_x) % a.tiles_y, si = a.S / per_img;
+    int ntx = s % a.tiles_x, nty = (s / a.tiles_x) % a.tiles_y, nimg = s / per_img;  // tile being staged
+
+    // one DMA piece of the tile at (img, y0, x0); `live` = false turns it into a zero fill (no HBM traffic)
+    auto piece = [&](int j, unsigned char* base, int img, int y0, int x0, bool live) {
+        if (j < NPW_P) {
+            const int pc = j * NW + wave;
+            if ((j + 1) * NW > NPC_P && pc >= NPC_P) return;  // ragged last P piece row (wave-uniform)
+            const int pixb = pc * 8, row0 = pixb / PHW, col0 = pixb - row0 * PHW;  // wave-uniform
+            int px = col0 + prow, py = row0;
+            if (px >= PHW) {
+                px -= PHW;
+                py += 1;
             }
+            const int gy = y0 - HALO + py, gx = x0 - HALO + px;
+            const bool ok = live && okcP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                            (NPP % 8 == 0 || pixb + prow < NPP);
+            const int ub = (img * a.PH + ps * (y0 - HALO) + pa) * a.PW + ps * (x0 - HALO) + pb;  // wave-uniform
+            const int e = ub + ps * (py * a.PW + px);
+            const char* src = ok ? lbaseP + (long)e * strideP : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
+        } else {
+            const int pc = (j - NPW_P) * NW + wave;
+            const int pixb = pc * 8, row0 = pixb / TW, col0 = pixb % TW;  // wave-uniform
+            const int gy = y0 + row0, gx = x0 + col0 + prow;
+            const bool ok = live && okcQ && gy < a.H && gx < a.W;
+            const int e = (img * a.H + gy) * a.W + gx;
+            const char* src = ok ? lbaseQ + (long)e * strideQ : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + PP_BYTES + pc * 1024), 16, 0, 0);
         }
     };
 
+    // wave decomposition: 8 waves = 2 (u halves) x 2 (v halves) x 2 (pixel halves, "k-split"); a wave owns a
+    // 32u x 32v accumulator for ALL taps (144 AGPRs for 3x3) over 8 of the 16 pixel rows.  Two waves per SIMD:
+    // one wave's address arithmetic / fragment shuffles run under the other wave's MFMAs.
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -321,88 +351,125 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgArgs a) {
     const int chA = wu * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
     const int chB = wv * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
     const int kx0 = 8 * h + tq;
+    static_assert((KH * TW) % 4 == 0 && (KH * PHW) % 4 == 0, "k-half offset must keep the swizzle phase");
 
     int buf = 0;
-    if (s < a.ntiles) stage(0, s);
+    if (s < a.ntiles) {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) piece(j, smem, nimg, nty * G::TH, ntx * TW, true);
+    }
     for (int tile = s; tile < a.ntiles; tile += a.S) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + a.S < a.ntiles) stage(buf ^ 1, tile + a.S);
-        const bf16* sP = reinterpret_cast<const bf16*>(smem + buf * BUF);
-        const bf16* sQ = reinterpret_cast<const bf16*>(smem + buf * BUF + PP_BYTES);
+        // advance the staging cursor to tile + S (its pieces are issued between the MFMAs below)
+        const bool more = tile + a.S < a.ntiles;
+        {
+            ntx += sx;
+            const int cx = ntx >= a.tiles_x;
+            ntx -= cx ? a.tiles_x : 0;
+            nty += sy + cx;
+            const int cy = nty >= a.tiles_y;
+            nty -= cy ? a.tiles_y : 0;
+            nimg += si + cy;
+        }
+        unsigned char* nbase = smem + (buf ^ 1) * BUF;
+        const int ny0 = nty * G::TH, nx0 = ntx * TW;
+        const bf16* sP = reinterpret_cast<const bf16*>(smem + buf * BUF) + (size_t)kh * KH * PHW * 64;
+        const bf16* sQ = reinterpret_cast<const bf16*>(smem + buf * BUF + PP_BYTES) + (size_t)kh * KH * TW * 64;
 
-        bf16x8 bfr[2], afr[2][NT];
-        auto fetch = [&](int slot, int y) {
+        // Row-major walk over the HALO rows of this k-half: halo row r feeds taps ky = r - y of the output rows
+        // y = r, r-1, r-2, so its 3 transposed reads (12 pixels -> the 3 kx fragments by in-register element
+        // shifts) are issued ONCE and reused by up to 18 MFMAs.  Raw reads for row r+1 are issued before the
+        // MFMAs of row r and only shuffled into fragments after them (one wave per SIMD: nothing else hides
+        // the LDS latency).
+        bf16x4 raw[3];
+        bf16x8 bfr[4];
+        auto readA = [&](int r) {
+            const int a0 = r * PHW + kx0, a1 = a0 + 4, a2 = a0 + 8;
+            raw[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
+            raw[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
+            if constexpr (NT == 9)
+                raw[2] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a2 * 64 + (chA ^ swz<T>(a2))));
+        };
+        auto readB = [&](int slot, int y) {
             const int q0 = y * TW + kx0, q1 = q0 + 4;
             const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q0 * 64 + (chB ^ swz<T>(q0))));
             const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q1 * 64 + (chB ^ swz<T>(q1))));
             bfr[slot] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-            if constexpr (NT == 9) {
-                // the three kx taps of a halo row read pixel windows shifted by one: fetch 12 pixels once (3 reads
-                // of 4) and build the 3 fragments with in-register element shifts instead of 6 reads
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int a0 = (y + ky) * PHW + kx0, a1 = a0 + 4, a2 = a0 + 8;
-                    const bf16x4 L = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
-                    const bf16x4 M = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
-                    const bf16x4 H = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a2 * 64 + (chA ^ swz<T>(a2))));
-                    const bf16x8 lm = __builtin_shufflevector(L, M, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8 mh = __builtin_shufflevector(M, H, 0, 1, 2, 3, 4, 5, 6, 7);
-                    afr[slot][ky * 3 + 0] = lm;
-                    afr[slot][ky * 3 + 1] = __builtin_shufflevector(lm, mh, 1, 2, 3, 4, 5, 6, 7, 12);
-                    afr[slot][ky * 3 + 2] = __builtin_shufflevector(lm, mh, 2, 3, 4, 5, 6, 7, 12, 13);
-                }
-            } else {
-                const int a0 = y * PHW + kx0, a1 = a0 + 4;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
-                afr[slot][0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
         };
-        constexpr int FIRST = (NT + 1) / 2;
-        if (a.debug & 4) {
-            buf ^= 1;
-            continue;
-        }
-        fetch(0, 0);
+        readA(0);
+        readB(0, 0);
 #pragma unroll
-        for (int y = 0; y < TH; ++y) {
-#pragma unroll
-            for (int t = 0; t < FIRST; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[y & 1][t], bfr[y & 1], acc[t], 0, 0, 0);
+        for (int r = 0; r < NR; ++r) {
+            bf16x8 af[3];
+            const bf16x8 lm = __builtin_shufflevector(raw[0], raw[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            af[0] = lm;
+            if constexpr (NT == 9) {
+                const bf16x8 mh = __builtin_shufflevector(raw[1], raw[2], 0, 1, 2, 3, 4, 5, 6, 7);
+                af[1] = __builtin_shufflevector(lm, mh, 1, 2, 3, 4, 5, 6, 7, 12);
+                af[2] = __builtin_shufflevector(lm, mh, 2, 3, 4, 5, 6, 7, 12, 13);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (y + 1 < TH) fetch((y + 1) & 1, y + 1);
+            if (r + 1 < NR) readA(r + 1);
+            if (r + 1 < KH) readB((r + 1) & 3, r + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = FIRST; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[y & 1][t], bfr[y & 1], acc[t], 0, 0, 0);
+            for (int jj = 0; jj < PPR; ++jj)
+                if (r * PPR + jj < NPW) piece(r * PPR + jj, nbase, nimg, ny0, nx0, more);
+#pragma unroll
+            for (int ky = 0; ky <= 2 * HALO; ++ky) {
+                const int y = r - ky;
+                if (y < 0 || y >= KH) continue;
+#pragma unroll
+                for (int kx = 0; kx <= 2 * HALO; ++kx)
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bfr[y & 3], acc[ky * 3 + kx], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         buf ^= 1;
     }
+    // sum the two pixel halves: the kh == 1 waves park their accumulators in the (now idle) ring, the kh == 0
+    // waves add them and write the slab.  [wu][t][j][e4][lane] float4 -> conflict-free 16-byte accesses.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)(wave & 3) * (NT * 4 * 64);
+    static_assert((size_t)4 * NT * 4 * 64 * 16 <= G::LDS, "reduction scratch must fit the ring");
+    if (kh == 1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
-            if (!(a.debug & 8)) a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
-        }
+            for (int e4 = 0; e4 < 4; ++e4) {
+                f32x4 v4 = {acc[t][e4 * 4 + 0], acc[t][e4 * 4 + 1], acc[t][e4 * 4 + 2], acc[t][e4 * 4 + 3]};
+                red[(t * 4 + e4) * 64 + lane] = v4;
+            }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 o = red[(t * 4 + e4) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i + 8 * e4 + 4 * h;
+                    const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
+                    if (!(a.debug & 8)) a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e4 * 4 + i] + o[i];
+                }
+            }
     }
 }
 
 template <int NT>
 int launch_dma(const WgArgs& a, hipStream_t s) {
-    constexpr int HALO = NT == 9 ? 1 : 0;
-    constexpr int NPP8 = ((16 + 2 * HALO) * (TW + 2 * HALO) + 7) / 8 * 8;
-    constexpr size_t lds = 2 * (size_t)(NPP8 * 128 + 16 * TW * 128);
+    constexpr size_t lds = DmaGeo<NT>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_dma_kernel<NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((wgrad_dma_kernel<NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), lds, s, a);
     HS_LAUNCH_CHECK("conv_wgrad_dma");
     return HIPSEG_OK;
 }
