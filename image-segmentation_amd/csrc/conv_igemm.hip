@@ -858,6 +858,305 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int
     if (pending) drain_tile();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weights-stationary 3x3 kernel for the <= 64-channel layers (the full-resolution layers of the U-Net).
+// There the implicit GEMM is short (K = 9 x 32..64) and the ring kernel spends as many LDS-DMA pieces on
+// re-fetching the weight chunk for every pixel tile as on the activations -- and LDS-DMA moves only ~11 B/clk
+// per CU, whatever the source.  Here every wave keeps the weights of its 32 output channels for ALL taps and
+// ALL input channels in registers (9 x K/16 MFMA B-fragments = 144 VGPRs at K = 64), loaded once per workgroup;
+// LDS holds nothing but a 3-deep ring of whole-K halo tiles (8 x 16 output pixels, 10 x 18 halo), filled by
+// LDS-DMA with per-lane constant source offsets.  Workgroups are persistent (2 x 4 waves per CU, independent
+// barriers, so one workgroup's epilogue stores run under the other's MFMAs) and walk a strided tile list;
+// one s_barrier per 128-pixel tile; the epilogue is wave-private (bf16 LDS transpose, 16-byte stores, BN
+// partial statistics in the same row convention as conv_epilogue).
+template <int KCH, int NB>
+struct WsGeo {
+    static constexpr int THS = 8, HWs = TW + 2, HHs = THS + 2, NPIX = HHs * HWs, NPIXP = (NPIX + 63) / 64 * 64;
+    static constexpr int NG = NPIXP / 64;                           // 64-pixel groups of the halo tile
+    static constexpr int NOCT = 2 * KCH, NW = 4, OPW = NOCT / NW;   // k-octets; octets per wave
+    static constexpr int A_BYTES = NOCT * NPIXP * 16, NAW = OPW * NG;  // DMA pieces per wave per tile
+    static constexpr int NBUF = 3, DIST = NBUF - 1;
+    static constexpr int WM = NW / NB, MT = (THS / 2) / WM;         // NB = 2: 2 x 2 waves, MT 2;  NB = 1: 4 x 1, MT 1
+    static constexpr int NACC = MT == 1 ? 2 : MT;                   // MT 1: two accumulators break the MFMA chain
+    static constexpr int DEPTH = MT == 1 ? 4 : 3;                   // fragment prefetch ring (steps)
+    static constexpr int SCR = 1024;                                // per-wave bf16 [16 px][32 ch] transpose tile
+    static constexpr int XCH = NB == 1 ? 2 * NW * 64 * 4 : 0;       // statistics exchange (NB = 1 wave pairs)
+    static constexpr size_t LDS = (size_t)NBUF * A_BYTES + NW * SCR + XCH;
+    static constexpr int NST = 2 * MT;                              // output stores per wave per tile
+    static_assert(NOCT % NW == 0 && LDS <= 80 * 1024, "geometry");
+};
+
+template <int KCH, int NB>
+__global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int total_tiles, int tiles_y8) {
+    typedef bf16 T;
+    typedef WsGeo<KCH, NB> G;
+    constexpr int MODE = HIPSEG_CONV3, NT = 9, HW = G::HWs, NPIXP = G::NPIXP, NG = G::NG, OPW = G::OPW;
+    constexpr int A_BYTES = G::A_BYTES, NAW = G::NAW, NBUF = G::NBUF, DIST = G::DIST, MT = G::MT, NACC = G::NACC;
+    constexpr int DEPTH = G::DEPTH, NST = G::NST, NQ = KCH * NT;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wn = wave % NB, wm = wave / NB;
+    const T* in0 = reinterpret_cast<const T*>(p.in0);
+    const T* in1 = reinterpret_cast<const T*>(p.in1);
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    const T* zero = reinterpret_cast<const T*>(&g_zero16);
+
+    // ---- stationary weights (packed [tap][Kp/8][Np][8]): lane (n = r, k-octet h) of every (tap, chunk) fragment
+    bf16x8 wreg[NT][KCH];
+    {
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.wp);
+        const int kgp = p.Kp / 8;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+            for (int c = 0; c < KCH; ++c)
+                wreg[tap][c] = *reinterpret_cast<const bf16x8*>(
+                    wp + (((size_t)tap * kgp + c * 2 + h) * p.Np + wn * 32 + r) * 16);
+    }
+    const int n = wn * 32 + r;  // this lane's output channel (accumulator column); N == Np is a launch condition
+    const float bv = p.bias ? p.bias[n] : 0.f;
+
+    // ---- per-lane DMA constants: pixel (py, px) of the halo tile for each 64-pixel group
+    int poff[NG], pyx[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int pix = g * 64 + lane, py = pix / HW, px = pix - py * HW;
+        poff[g] = py * p.W + px;
+        pyx[g] = pix < G::NPIX ? (py | (px << 8)) : (0x7f | (0x7f << 8));  // pad pixels: always out of range
+    }
+    // A-fragment pixel of each M sub-tile (rows r of the MFMA; see sub_px)
+    int hbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int py = 2 * (wm * MT + i) + (r >> 4), px = sub_px<MODE>(r);
+        hbase[i] = (h * NPIXP + py * HW + px) * 16;
+    }
+
+    // ---- tile cursors (incremental: no per-tile divisions).  c = compute cursor, n = staging cursor (DIST ahead)
+    struct Cur {
+        int tile, tx, ty, img;
+    };
+    const int per_img = p.tiles_x * tiles_y8, GS = gridDim.x;
+    const int sx = GS % p.tiles_x, sy = (GS / p.tiles_x) % tiles_y8, si = GS / per_img;
+    auto advance = [&](Cur& c) {
+        c.tile += GS;
+        c.tx += sx;
+        const int cx = c.tx >= p.tiles_x;
+        c.tx -= cx ? p.tiles_x : 0;
+        c.ty += sy + cx;
+        const int cy = c.ty >= tiles_y8;
+        c.ty -= cy ? tiles_y8 : 0;
+        c.img += si + cy;
+    };
+    Cur cc, cn;
+    cc.tile = blockIdx.x;
+    cc.tx = cc.tile % p.tiles_x;
+    cc.ty = (cc.tile / p.tiles_x) % tiles_y8;
+    cc.img = cc.tile / per_img;
+    cn = cc;
+
+    // one 1-KiB piece (octet, 64-pixel group) of the tile under the staging cursor
+    auto piece = [&](int j, unsigned char* base, int img, int y0, int x0, bool live) {
+        const int oct = wave * OPW + j / NG, g = j % NG;
+        const int c0 = oct * 8;  // wave-uniform
+        const T* src0;
+        int cs;
+        if (c0 < p.C0) {
+            src0 = in0 + c0;
+            cs = p.C0;
+        } else {
+            src0 = in1 + (c0 - p.C0);
+            cs = p.C1;
+        }
+        const int gy = y0 - 1 + (pyx[g] & 0xff), gx = x0 - 1 + (pyx[g] >> 8);
+        const bool ok = live && c0 < p.K && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int e = (img * p.H + y0 - 1) * p.W + x0 - 1 + poff[g];
+        const T* src = ok ? src0 + (long)e * cs : zero;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + (oct * NG + g) * 1024), 16, 0, 0);
+    };
+
+    // prologue: DIST tiles go out at once
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) {
+        const bool live = cn.tile < total_tiles;
+#pragma unroll
+        for (int j = 0; j < NAW; ++j) piece(j, smem + d * A_BYTES, cn.img, cn.ty * G::THS, cn.tx * TW, live);
+        advance(cn);
+    }
+
+    unsigned char* scr = smem + NBUF * A_BYTES + wave * G::SCR;
+    float* xch = reinterpret_cast<float*>(smem + NBUF * A_BYTES + G::NW * G::SCR);
+    const int tiles_y16 = (p.H + 15) / 16;
+    int cur = 0, it = 0;
+    int hist = 0;                // bit k: the tile k+1 iterations back was interior (issued all its stores)
+    size_t pend_row = 0;         // NB == 1: statistics row of the previous tile, written after the next barrier
+    bool pend = false;
+    for (; cc.tile < total_tiles; advance(cc), ++it) {
+        // Counted wait for this tile's pieces.  VMEM ops retire in issue order; per wave the ops younger than
+        // P(tile k) are: S(k-2) [+ statistics stores], P(k+1), S(k-1) [+ statistics stores] (and, NB == 1, the
+        // paired statistics stores X(k-2) of the even waves).  The count is exact only when both previous tiles
+        // were interior (every predicated store really issued); otherwise, and for the first two tiles, drain.
+        if (hist == 3) {
+            constexpr int BASE = (DIST - 1) * NAW + DIST * NST;
+            if (!p.stats)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+            else if (NB == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + DIST * 2) : "memory");
+            else if (!(wave & 1))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + (DIST - 1) * 2) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (NB == 1 && p.stats && pend && !(wave & 1)) {
+            // wave pair (wm, wm + 1) = one 64-pixel statistics group: the odd wave parked its partial sums
+            const float* mine = xch + (((it - 1) & 1) * G::NW + wave) * 64;
+            const float* other = mine + 64;
+            if (h == 0) {
+                p.stats[(pend_row * 2 + 0) * p.N + n] = mine[r] + other[r];
+                p.stats[(pend_row * 2 + 1) * p.N + n] = mine[32 + r] + other[32 + r];
+            }
+        }
+        const bool more = cn.tile < total_tiles;
+        unsigned char* nbase = smem + ((cur + DIST) % NBUF) * A_BYTES;
+        const int ny0 = cn.ty * G::THS, nx0 = cn.tx * TW, nimg = cn.img;
+        const unsigned char* sA = smem + cur * A_BYTES;
+        cur = (cur + 1) % NBUF;
+
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        // step q = (chunk, tap): MT reads + MT MFMAs; fragments are fetched DEPTH - 1 steps ahead
+        bf16x8 af[DEPTH][MT];
+        auto fetch = [&](int slot, int q) {
+            const int c = q / NT, tap = q % NT;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + hbase[i] + (c * 2 * NPIXP + tap_off<MODE>(tap)) * 16);
+        };
+#pragma unroll
+        for (int q = 0; q < DEPTH - 1; ++q) fetch(q, q);
+        constexpr int PSTEP = NQ / NAW;  // a DMA piece every PSTEP steps
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + DEPTH - 1 < NQ) fetch((q + DEPTH - 1) % DEPTH, q + DEPTH - 1);
+            if (q % PSTEP == 0 && q / PSTEP < NAW) piece(q / PSTEP, nbase, nimg, ny0, nx0, more);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ai = MT == 1 ? (q & 1) : i;
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q % DEPTH][i], wreg[q % NT][q / NT], acc[ai], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_assert((NAW - 1) * PSTEP < NQ, "all pieces issued inside the step walk");
+        advance(cn);
+        if (MT == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
+        }
+
+        // ---- wave-private epilogue
+        const int y0 = cc.ty * G::THS, x0 = cc.tx * TW, img = cc.img;
+        float ssum = 0.f, ssq = 0.f;
+        const bool interior = y0 + G::THS <= p.H && x0 + TW <= p.W;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int yb = y0 + 2 * (wm * MT + i);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
+                    const float v = acc[i][e] + bv;
+                    reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
+                    if (yb + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
+                        ssum += v;
+                        ssq += v * v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int px = lane >> 2, cv = lane & 3;
+                    const bf16x8 o = *reinterpret_cast<const bf16x8*>(scr + (px * 32 + cv * 8) * 2);
+                    const int y = yb + half, x = x0 + sub_px<MODE>(half * 16 + px);
+                    const int nn = wn * 32 + cv * 8;
+                    if (y < p.H && x < p.W) {
+                        const long opix = ((long)img * p.H + y) * p.W + x;
+                        T* dst = (nn < p.N0) ? out0 + opix * p.N0 + nn : out1 + opix * p.N1 + (nn - p.N0);
+                        *reinterpret_cast<bf16x8*>(dst) = o;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (p.stats) {
+            const float S = ssum + __shfl_xor(ssum, 32, 64);
+            const float Q = ssq + __shfl_xor(ssq, 32, 64);
+            // 64-pixel statistics group of this wave inside the 16x16 tile grid (see conv_epilogue)
+            const int Gi = (y0 & 15) / 4 + (NB == 2 ? wm : wm / 2);
+            const size_t row = (((size_t)img * tiles_y16 + y0 / 16) * p.tiles_x + x0 / 16) * 4 + Gi;
+            if (NB == 2) {
+                if (h == 0) {
+                    p.stats[(row * 2 + 0) * p.N + n] = S;
+                    p.stats[(row * 2 + 1) * p.N + n] = Q;
+                }
+            } else {
+                float* slot = xch + ((it & 1) * G::NW + wave) * 64;
+                if (h == 0) {
+                    slot[r] = S;
+                    slot[32 + r] = Q;
+                }
+                pend_row = row;
+                pend = true;
+            }
+        }
+        hist = ((hist << 1) | (interior ? 1 : 0)) & 3;
+    }
+    if (NB == 1 && p.stats && pend) {
+        __syncthreads();
+        if (!(wave & 1) && h == 0) {
+            const float* mine = xch + (((it - 1) & 1) * G::NW + wave) * 64;
+            const float* other = mine + 64;
+            p.stats[(pend_row * 2 + 0) * p.N + n] = mine[r] + other[r];
+            p.stats[(pend_row * 2 + 1) * p.N + n] = mine[32 + r] + other[32 + r];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KCH, int NB>
+int launch_wstat(const ConvArgs& a, hipStream_t s) {
+    typedef WsGeo<KCH, NB> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+        attr_set = true;
+    }
+    // whole 16-row tiles: every statistics row of the 16x16 tile grid gets written (zeros outside the image)
+    const int tiles_y8 = 2 * cdiv(a.H, 16);
+    const long total = (long)a.B * a.tiles_x * tiles_y8;
+    const long grid = total < 2 * a.ncu ? total : 2 * a.ncu;
+    hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB>), dim3((unsigned)grid), dim3(256), G::LDS, s, a, (int)total, tiles_y8);
+    HS_LAUNCH_CHECK("conv3_wstat");
+    return HIPSEG_OK;
+}
+
 template <int MODE, int BN, int THT>
 int launch_pers(const ConvArgs& a0, hipStream_t s) {
     constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT);
@@ -1041,6 +1340,14 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
             if (mode == HIPSEG_CONV3 && H >= 32 && !no_tall)
                 return bn == 64 ? launch_pers<HIPSEG_CONV3, 64, 32>(a, s) : launch_pers<HIPSEG_CONV3, 32, 32>(a, s);
+        }
+        // <= 64-channel 3x3 layers with enough 128-pixel tiles for two persistent workgroups per CU: weights-stationary
+        static const bool no_wstat = getenv("HIPSEG_NO_WSTAT") != nullptr;
+        if (mode == HIPSEG_CONV3 && a.vec_ok && !no_dma && !no_wstat && !dbg && N0 % 8 == 0 && N1 % 8 == 0 &&
+            a.N == a.Np && (a.Np == 32 || a.Np == 64) && (a.Kp == 32 || a.Kp == 64) &&
+            (long)B * a.tiles_x * 2 * cdiv(H, 16) >= 4 * a.ncu) {
+            if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
+            return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
         }
         if (a.vec_ok && !no_dma) {
             // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)

@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int TW = 16;
+#ifndef NPW_PPR
+#define NPW_PPR 4
+#endif
 
 template <typename T>
 struct WT;
@@ -239,27 +242,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
 // SOURCE chunk (LDS destination stays linear), out-of-image / padded channels read a zero word.
 __device__ uint4 g_wg_zero16 = {0u, 0u, 0u, 0u};
 
-template <int NT>
+template <int NT, int UB, int VB>
 struct DmaGeo {
-    static constexpr int TH = 16, KH = TH / 2;               // pixel rows per tile / per k-half
+    static constexpr int TH = 16, NW = 8;
+    static constexpr int KS = NW / (UB * VB), KH = TH / KS;  // pixel-row split ("k-split") and rows per wave
     static constexpr int HALO = NT == 9 ? 1 : 0;
     static constexpr int PHW = TW + 2 * HALO, NPP = (TH + 2 * HALO) * PHW, NPQ = TH * TW;
-    static constexpr int NW = 8;                             // waves: 2 (u) x 2 (v) x 2 (pixel halves)
-    static constexpr int NPC_P = (NPP + 7) / 8, NPC_Q = NPQ / 8;  // 1-KiB DMA pieces of the P / Q image
-    static constexpr int NPW_P = (NPC_P + NW - 1) / NW, NPW_Q = NPC_Q / NW, NPW = NPW_P + NPW_Q;  // per wave
-    static constexpr int PP_BYTES = NPC_P * 1024, Q_BYTES = NPQ * 128, BUF = PP_BYTES + Q_BYTES;
-    static constexpr int NR = KH + 2 * HALO;                 // halo rows a k-half walks
-    static constexpr int PPR = (NPW + NR - 1) / NR;          // DMA pieces issued per halo row
-    static constexpr size_t LDS = 2 * (size_t)BUF;
+    static constexpr int PCH = 32 * UB, QCH = 32 * VB;                 // channels per LDS pixel row
+    static constexpr int PPX = 512 / PCH, QPX = 512 / QCH;             // pixels per 1-KiB DMA piece
+    static constexpr int NPC_P = (NPP + PPX - 1) / PPX, NPC_Q = NPQ / QPX;
+    static constexpr int NPW_P = (NPC_P + NW - 1) / NW, NPW_Q = (NPC_Q + NW - 1) / NW, NPW = NPW_P + NPW_Q;
+    static constexpr int PP_BYTES = NPC_P * 1024, Q_BYTES = NPC_Q * 1024, BUF = PP_BYTES + Q_BYTES;
+    static constexpr int NR = KH + 2 * HALO;                           // halo rows a wave walks per tile
+    // DMA pieces issued per halo row: everything goes out in the FIRST rows of the walk, so a piece has most of a
+    // tile's MFMA time (plus DIST - 1 whole tiles) to land; spread over all rows the last pieces would be issued
+    // just before the barrier that waits for them (measured: the whole HBM latency exposed per tile).
+    static constexpr int PPR_ = NPW_PPR;
+    static constexpr int PPR = PPR_ < (NPW + NR - 1) / NR ? (NPW + NR - 1) / NR : PPR_;
+    static constexpr int NBUF_FIT = (160 * 1024 - 1024) / BUF;
+    static constexpr int NBUF = NBUF_FIT >= 4 ? 4 : (NBUF_FIT >= 3 ? 3 : 2), DIST = NBUF - 1;
+    static constexpr size_t RED_BYTES = (size_t)4 * NT * 16 * 64 * 4;  // 4 parked accumulator sets
+    static constexpr size_t RING_BYTES = (size_t)NBUF * BUF + 1024;    // + 1-KiB sink for pad pieces
+    static constexpr size_t LDS = RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES;
+    static_assert(NPQ % QPX == 0 && LDS <= 160 * 1024, "geometry");
 };
 
-template <int NT>
+// UB x VB = 32-channel blocks of the workgroup tile (1 or 2 each): 64u x 64v runs 2x2 waves x 2 pixel halves,
+// a 32-channel side gives its waves to the pixel split instead (no MFMA work on padding channels) and its LDS
+// image shrinks to 64 B per pixel (no swizzle needed), which also deepens the ring (up to 4 tiles in flight).
+template <int NT, int UB, int VB, bool DBG>
 __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     typedef bf16 T;
-    typedef DmaGeo<NT> G;
-    constexpr int UC = 64, VC = 64, KH = G::KH, HALO = G::HALO, PHW = G::PHW, NPP = G::NPP;
+    typedef DmaGeo<NT, UB, VB> G;
+    constexpr int KH = G::KH, HALO = G::HALO, PHW = G::PHW, NPP = G::NPP, PCH = G::PCH, QCH = G::QCH;
     constexpr int PP_BYTES = G::PP_BYTES, BUF = G::BUF, NPW_P = G::NPW_P, NPW = G::NPW, NR = G::NR, PPR = G::PPR;
-    constexpr int NW = G::NW, NPC_P = G::NPC_P;
+    constexpr int NW = G::NW, NPC_P = G::NPC_P, NPC_Q = G::NPC_Q, NBUF = G::NBUF, DIST = G::DIST;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -268,21 +285,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int wu = wave & 1, wv = (wave >> 1) & 1, kh = wave >> 2;
+    const int uv = wave % (UB * VB), wu = uv % UB, wv = uv / UB, kh = wave / (UB * VB);
     const int vt = blockIdx.x % a.VT;
     const int ut = (blockIdx.x / a.VT) % a.UT;
     const int s = blockIdx.x / (a.VT * a.UT);
-    const int u0 = ut * UC, v0 = vt * VC;
+    const int u0 = ut * PCH, v0 = vt * QCH;
     const char* zero = reinterpret_cast<const char*>(&g_wg_zero16);
+    unsigned char* sink = smem + NBUF * BUF;
 
     // ---- staging addresses.  Everything that does not change from tile to tile is folded into per-lane constants
     // (source base incl. channel, pixel stride, channel validity); a piece then costs ~a dozen VALU ops.
-    // A lane copies 16 B = 8 channels of pixel row `prow` of its wave's 8-pixel piece; the XOR swizzle of the
-    // image is applied to the SOURCE chunk and depends on bit 1 of the pixel index = bit 1 of prow only.
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const int lch = (pchunk ^ (((prow >> 1) & 1) << 2)) * 8;
-    const int cP = u0 + lch, cQ = v0 + lch;
-    const bool okcP = cP < a.CU && !(a.debug & 1), okcQ = cQ < a.CV && !(a.debug & 2);
+    // A lane copies 16 B = 8 channels of one pixel of its wave's piece; for the 128-B (64-channel) rows the XOR
+    // swizzle of the image is applied to the SOURCE chunk and depends on bit 1 of the pixel index only, which is
+    // bit 1 of the lane's pixel row inside the piece.
+    constexpr int LPP_P = PCH / 8, LPP_Q = QCH / 8;  // lanes per pixel
+    const int prowP = lane / LPP_P, prowQ = lane / LPP_Q;
+    const int lchP = (PCH == 64 ? ((lane % LPP_P) ^ (((prowP >> 1) & 1) << 2)) : (lane % LPP_P)) * 8;
+    const int lchQ = (QCH == 64 ? ((lane % LPP_Q) ^ (((prowQ >> 1) & 1) << 2)) : (lane % LPP_Q)) * 8;
+    const int cP = u0 + lchP, cQ = v0 + lchQ;
+    const bool okcP = cP < a.CU && !(DBG && (a.debug & 1)), okcQ = cQ < a.CV && !(DBG && (a.debug & 2));
     const char* lbaseP;
     int strideP;  // bytes between consecutive P "pixels"
     int ps = a.ps, pa = a.pa;
@@ -306,40 +327,53 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     // tile walk tile = s, s + S, ... as incremental (tx, ty, img) updates (no per-tile divisions)
     const int per_img = a.tiles_x * a.tiles_y;
     const int sx = a.S % a.tiles_x, sy = (a.S / a.tiles_x) % a.tiles_y, si = a.S / per_img;
-    int ntx = s % a.tiles_x, nty = (s / a.tiles_x) % a.tiles_y, nimg = s / per_img;  // tile being staged
+    int ntx = s % a.tiles_x, nty = (s / a.tiles_x) % a.tiles_y, nimg = s / per_img, ntile = s;  // staging cursor
+    auto advance = [&]() {
+        ntile += a.S;
+        ntx += sx;
+        const int cx = ntx >= a.tiles_x;
+        ntx -= cx ? a.tiles_x : 0;
+        nty += sy + cx;
+        const int cy = nty >= a.tiles_y;
+        nty -= cy ? a.tiles_y : 0;
+        nimg += si + cy;
+    };
 
-    // one DMA piece of the tile at (img, y0, x0); `live` = false turns it into a zero fill (no HBM traffic)
+    // one DMA piece of the tile at (img, y0, x0); `live` = false turns it into a zero fill (no HBM traffic).
+    // Every wave issues exactly NPW pieces per tile (ragged piece rows go to the sink) so that "tile landed"
+    // is a counted vmcnt wait.
     auto piece = [&](int j, unsigned char* base, int img, int y0, int x0, bool live) {
         if (j < NPW_P) {
             const int pc = j * NW + wave;
-            if ((j + 1) * NW > NPC_P && pc >= NPC_P) return;  // ragged last P piece row (wave-uniform)
-            const int pixb = pc * 8, row0 = pixb / PHW, col0 = pixb - row0 * PHW;  // wave-uniform
-            int px = col0 + prow, py = row0;
+            const bool real = (j + 1) * NW <= NPC_P || pc < NPC_P;  // wave-uniform
+            const int pixb = pc * G::PPX, row0 = pixb / PHW, col0 = pixb - row0 * PHW;  // wave-uniform
+            int px = col0 + prowP, py = row0;
             if (px >= PHW) {
                 px -= PHW;
                 py += 1;
             }
             const int gy = y0 - HALO + py, gx = x0 - HALO + px;
-            const bool ok = live && okcP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-                            (NPP % 8 == 0 || pixb + prow < NPP);
+            const bool ok = live && real && okcP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                            (NPP % G::PPX == 0 || pixb + prowP < NPP);
             const int ub = (img * a.PH + ps * (y0 - HALO) + pa) * a.PW + ps * (x0 - HALO) + pb;  // wave-uniform
             const int e = ub + ps * (py * a.PW + px);
             const char* src = ok ? lbaseP + (long)e * strideP : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + pc * 1024 : sink), 16, 0, 0);
         } else {
             const int pc = (j - NPW_P) * NW + wave;
-            const int pixb = pc * 8, row0 = pixb / TW, col0 = pixb % TW;  // wave-uniform
-            const int gy = y0 + row0, gx = x0 + col0 + prow;
-            const bool ok = live && okcQ && gy < a.H && gx < a.W;
+            const bool real = (j - NPW_P + 1) * NW <= NPC_Q || pc < NPC_Q;  // wave-uniform
+            const int pixb = pc * G::QPX, row0 = pixb / TW, col0 = pixb % TW;  // wave-uniform
+            const int gy = y0 + row0, gx = x0 + col0 + prowQ;
+            const bool ok = live && real && okcQ && gy < a.H && gx < a.W;
             const int e = (img * a.H + gy) * a.W + gx;
             const char* src = ok ? lbaseQ + (long)e * strideQ : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + PP_BYTES + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + PP_BYTES + pc * 1024 : sink), 16, 0,
+                                             0);
         }
     };
 
-    // wave decomposition: 8 waves = 2 (u halves) x 2 (v halves) x 2 (pixel halves, "k-split"); a wave owns a
-    // 32u x 32v accumulator for ALL taps (144 AGPRs for 3x3) over 8 of the 16 pixel rows.  Two waves per SIMD:
-    // one wave's address arithmetic / fragment shuffles run under the other wave's MFMAs.
+    // a wave owns a 32u x 32v accumulator for ALL taps (144 AGPRs for 3x3) over KH of the 16 pixel rows.  Two
+    // waves per SIMD: one wave's address arithmetic / fragment shuffles run under the other wave's MFMAs.
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -351,50 +385,49 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     const int chA = wu * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
     const int chB = wv * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;
     const int kx0 = 8 * h + tq;
-    static_assert((KH * TW) % 4 == 0 && (KH * PHW) % 4 == 0, "k-half offset must keep the swizzle phase");
+    static_assert((KH * TW) % 4 == 0 && (KH * PHW) % 4 == 0, "k-split offset must keep the swizzle phase");
+    auto swzP = [](int pix) { return PCH == 64 ? ((pix >> 1) & 1) << 5 : 0; };
+    auto swzQ = [](int pix) { return QCH == 64 ? ((pix >> 1) & 1) << 5 : 0; };
 
-    int buf = 0;
-    if (s < a.ntiles) {
+    // prologue: the first DIST tiles go out at once
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) piece(j, smem, nimg, nty * G::TH, ntx * TW, true);
+    for (int d = 0; d < DIST; ++d) {
+        const bool live = ntile < a.ntiles;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) piece(j, smem + d * BUF, nimg, nty * G::TH, ntx * TW, live);
+        advance();
     }
+    int cur = 0;
     for (int tile = s; tile < a.ntiles; tile += a.S) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // advance the staging cursor to tile + S (its pieces are issued between the MFMAs below)
-        const bool more = tile + a.S < a.ntiles;
-        {
-            ntx += sx;
-            const int cx = ntx >= a.tiles_x;
-            ntx -= cx ? a.tiles_x : 0;
-            nty += sy + cx;
-            const int cy = nty >= a.tiles_y;
-            nty -= cy ? a.tiles_y : 0;
-            nimg += si + cy;
-        }
-        unsigned char* nbase = smem + (buf ^ 1) * BUF;
+        // tile's pieces are the oldest outstanding ones; DIST - 1 younger tiles stay in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // staging target: the slot every wave has just left; its pieces are issued between the MFMAs below
+        const bool more = ntile < a.ntiles;
+        unsigned char* nbase = smem + ((cur + DIST) % NBUF) * BUF;
         const int ny0 = nty * G::TH, nx0 = ntx * TW;
-        const bf16* sP = reinterpret_cast<const bf16*>(smem + buf * BUF) + (size_t)kh * KH * PHW * 64;
-        const bf16* sQ = reinterpret_cast<const bf16*>(smem + buf * BUF + PP_BYTES) + (size_t)kh * KH * TW * 64;
+        const bf16* sP = reinterpret_cast<const bf16*>(smem + cur * BUF) + (size_t)kh * KH * PHW * PCH;
+        const bf16* sQ = reinterpret_cast<const bf16*>(smem + cur * BUF + PP_BYTES) + (size_t)kh * KH * TW * QCH;
+        cur = (cur + 1) % NBUF;
 
-        // Row-major walk over the HALO rows of this k-half: halo row r feeds taps ky = r - y of the output rows
-        // y = r, r-1, r-2, so its 3 transposed reads (12 pixels -> the 3 kx fragments by in-register element
-        // shifts) are issued ONCE and reused by up to 18 MFMAs.  Raw reads for row r+1 are issued before the
-        // MFMAs of row r and only shuffled into fragments after them (one wave per SIMD: nothing else hides
-        // the LDS latency).
+        // Row-major walk over the HALO rows of this wave's pixel rows: halo row r feeds taps ky = r - y of the
+        // output rows y = r, r-1, r-2, so its 3 transposed reads (12 pixels -> the 3 kx fragments by in-register
+        // element shifts) are issued ONCE and reused by up to 9 MFMAs.  Raw reads for row r+1 are issued before
+        // the MFMAs of row r and only shuffled into fragments after them.
         bf16x4 raw[3];
         bf16x8 bfr[4];
         auto readA = [&](int r) {
             const int a0 = r * PHW + kx0, a1 = a0 + 4, a2 = a0 + 8;
-            raw[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * 64 + (chA ^ swz<T>(a0))));
-            raw[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * 64 + (chA ^ swz<T>(a1))));
+            raw[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a0 * PCH + (chA ^ swzP(a0))));
+            raw[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a1 * PCH + (chA ^ swzP(a1))));
             if constexpr (NT == 9)
-                raw[2] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a2 * 64 + (chA ^ swz<T>(a2))));
+                raw[2] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sP + (size_t)a2 * PCH + (chA ^ swzP(a2))));
         };
         auto readB = [&](int slot, int y) {
             const int q0 = y * TW + kx0, q1 = q0 + 4;
-            const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q0 * 64 + (chB ^ swz<T>(q0))));
-            const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q1 * 64 + (chB ^ swz<T>(q1))));
+            const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q0 * QCH + (chB ^ swzQ(q0))));
+            const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sQ + (size_t)q1 * QCH + (chB ^ swzQ(q1))));
             bfr[slot] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
         readA(0);
@@ -416,6 +449,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
 #pragma unroll
             for (int jj = 0; jj < PPR; ++jj)
                 if (r * PPR + jj < NPW) piece(r * PPR + jj, nbase, nimg, ny0, nx0, more);
+            if (DBG && (a.debug & 4)) continue;  // ablation build only (splits the scheduling region)
 #pragma unroll
             for (int ky = 0; ky <= 2 * HALO; ++ky) {
                 const int y = r - ky;
@@ -426,52 +460,74 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        buf ^= 1;
+        static_assert(NR * PPR >= NPW, "all pieces of a tile are issued inside its row walk");
+        advance();
     }
-    // sum the two pixel halves: the kh == 1 waves park their accumulators in the (now idle) ring, the kh == 0
-    // waves add them and write the slab.  [wu][t][j][e4][lane] float4 -> conflict-free 16-byte accesses.
+    // sum the KS pixel-row partials through LDS (binary tree): the upper half of the remaining waves park their
+    // accumulators in the (now idle) ring, the lower half add them; the kh == 0 waves write the slab.
+    // [slot][t][e4][lane] float4 -> conflict-free 16-byte accesses.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)(wave & 3) * (NT * 4 * 64);
-    static_assert((size_t)4 * NT * 4 * 64 * 16 <= G::LDS, "reduction scratch must fit the ring");
-    if (kh == 1) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int step = G::KS / 2; step >= 1; step >>= 1) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)(((kh & (step - 1)) * (UB * VB) + uv)) * (NT * 4 * 64);
+        if (kh >= step && kh < 2 * step) {
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                f32x4 v4 = {acc[t][e4 * 4 + 0], acc[t][e4 * 4 + 1], acc[t][e4 * 4 + 2], acc[t][e4 * 4 + 3]};
-                red[(t * 4 + e4) * 64 + lane] = v4;
-            }
-    }
-    __syncthreads();
-    if (kh == 0) {
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 o = red[(t * 4 + e4) * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = i + 8 * e4 + 4 * h;
-                    const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
-                    if (!(a.debug & 8)) a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e4 * 4 + i] + o[i];
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    f32x4 v4 = {acc[t][e4 * 4 + 0], acc[t][e4 * 4 + 1], acc[t][e4 * 4 + 2], acc[t][e4 * 4 + 3]};
+                    red[(t * 4 + e4) * 64 + lane] = v4;
                 }
+        }
+        __syncthreads();
+        if (kh < step) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const f32x4 o = red[(t * 4 + e4) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][e4 * 4 + i] += o[i];
+                }
+        }
+    }
+    if (kh == 0 && !(DBG && (a.debug & 8))) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int u = u0 + wu * 32 + row, v = v0 + wv * 32 + (lane & 31);
+                a.slabs[(((size_t)s * NT + t) * a.CUp + u) * a.CVp + v] = acc[t][e];
             }
     }
 }
 
-template <int NT>
+template <int NT, int UB, int VB>
 int launch_dma(const WgArgs& a, hipStream_t s) {
-    constexpr size_t lds = DmaGeo<NT>::LDS;
+    constexpr size_t lds = DmaGeo<NT, UB, VB>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_dma_kernel<NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), lds, s, a);
+    const dim3 grid((unsigned)(a.S * a.UT * a.VT));
+    if (a.debug)
+        hipLaunchKernelGGL((wgrad_dma_kernel<NT, UB, VB, true>), grid, dim3(512), lds, s, a);
+    else
+        hipLaunchKernelGGL((wgrad_dma_kernel<NT, UB, VB, false>), grid, dim3(512), lds, s, a);
     HS_LAUNCH_CHECK("conv_wgrad_dma");
     return HIPSEG_OK;
+}
+
+template <int NT>
+int launch_dma_blocks(const WgArgs& a, int UB, int VB, hipStream_t s) {
+    if (UB == 2) return VB == 2 ? launch_dma<NT, 2, 2>(a, s) : launch_dma<NT, 2, 1>(a, s);
+    return VB == 2 ? launch_dma<NT, 1, 2>(a, s) : launch_dma<NT, 1, 1>(a, s);
 }
 
 // sum the S slabs in fixed order and scatter into the parameter's native layout
@@ -595,7 +651,19 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     HS_REQUIRE(B > 0 && H > 0 && W > 0, "conv_wgrad: empty pixel grid");
     const int CU = mode == HIPSEG_CONVT ? 4 * CU0 : CU0 + CU1;
     HS_REQUIRE(!(mode == HIPSEG_CONVT && CU1 != 0), "conv_wgrad: CONVT takes a single P tensor");
-    const Plan pl = plan_for(dtype, mode, CU, CV, B, H, W);
+    Plan pl = plan_for(dtype, mode, CU, CV, B, H, W);
+    const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
+    static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;
+    const bool dma = dtype == HIPSEG_BF16 && CU0 % vec == 0 && CU1 % vec == 0 && CV % vec == 0 && !no_dma;
+    // DMA kernel: the workgroup tile is UB x VB 32-channel blocks (a <= 32-channel side is not padded to 64).
+    // Never needs more slab space than the generic plan hipseg_wgrad_workspace_elems() sizes for.
+    const int UB = CU > 32 ? 2 : 1, VB = CV > 32 ? 2 : 1;
+    if (dma) {
+        pl.UT = cdiv(CU, 32 * UB);
+        pl.VT = cdiv(CV, 32 * VB);
+        pl.CUp = pl.UT * 32 * UB;
+        pl.CVp = pl.VT * 32 * VB;
+    }
     WgArgs a;
     a.p0 = p0;
     a.p1 = p1;
@@ -621,7 +689,6 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     a.S = pl.S;
     a.UT = pl.UT;
     a.VT = pl.VT;
-    const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
     a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
     a.vec_ok_q = (CV % vec == 0);
     a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
@@ -632,9 +699,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     for (int ab = 0; ab < 1; ++ab) {
         int rc;
-        static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;
-        if (dtype == HIPSEG_BF16 && a.vec_ok_p && a.vec_ok_q && !no_dma)
-            rc = pl.NT == 9 ? launch_dma<9>(a, s) : launch_dma<1>(a, s);
+        if (dma)
+            rc = pl.NT == 9 ? launch_dma_blocks<9>(a, UB, VB, s) : launch_dma_blocks<1>(a, UB, VB, s);
         else if (dtype == HIPSEG_BF16)
             rc = pl.NT == 9 ? launch<bf16, 9>(a, s) : launch<bf16, 1>(a, s);
         else

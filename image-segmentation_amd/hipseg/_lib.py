@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_
 import torch  # noqa: F401  (must precede ctypes.CDLL below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhipseg.so")
+LIB_PATH = os.environ.get("HIPSEG_LIB") or os.path.join(HERE, "lib", "libhipseg.so")  # HIPSEG_LIB: A/B builds
 
 F32, BF16 = 0, 1
 CONV3, CONV1, CONV2S2, CONVT = 0, 1, 2, 3

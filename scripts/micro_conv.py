@@ -41,4 +41,5 @@ for name, B, ci, co, H in LAYERS:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * H * H * ci * co * 9
-    print(f"{which} {name:8s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TF/s  dbg={os.environ.get('HIPSEG_IGEMM_DEBUG','0')}")
+    dbg = os.environ.get("HIPSEG_IGEMM_DEBUG", "0") + "/" + os.environ.get("HIPSEG_WGRAD_DEBUG", "0")
+    print(f"{which} {name:8s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TF/s  dbg={dbg}", flush=True)

@@ -68,6 +68,12 @@ CONV_CASES = [
     (1, 128, 0, 256, 8, 8),
     (1, 24, 0, 40, 16, 16),
     (1, 5, 0, 7, 10, 18),
+    # >= 1024 tiles of 8x16 pixels with <= 64 channels: the weights-stationary persistent kernel (all four
+    # K/N shapes between fwd and dgrad, dual source / dual destination, ragged image borders)
+    (2, 64, 0, 64, 256, 256),
+    (2, 32, 0, 64, 256, 256),
+    (4, 32, 32, 32, 130, 250),
+    (3, 32, 0, 32, 200, 232),
 ]
 
 
