@@ -880,13 +880,12 @@ struct WsGeo {
     static constexpr int NACC = MT == 1 ? 2 : MT;                   // MT 1: two accumulators break the MFMA chain
     static constexpr int DEPTH = MT == 1 ? 4 : 3;                   // fragment prefetch ring (steps)
     static constexpr int SCR = 1024;                                // per-wave bf16 [16 px][32 ch] transpose tile
-    static constexpr int XCH = NB == 1 ? 2 * NW * 64 * 4 : 0;       // statistics exchange (NB = 1 wave pairs)
-    static constexpr size_t LDS = (size_t)NBUF * A_BYTES + NW * SCR + XCH;
+    static constexpr size_t LDS = (size_t)NBUF * A_BYTES + NW * SCR;
     static constexpr int NST = 2 * MT;                              // output stores per wave per tile
     static_assert(NOCT % NW == 0 && LDS <= 80 * 1024, "geometry");
 };
 
-template <int KCH, int NB>
+template <int KCH, int NB, bool DBG>
 __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int total_tiles, int tiles_y8) {
     typedef bf16 T;
     typedef WsGeo<KCH, NB> G;
@@ -975,7 +974,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
             cs = p.C1;
         }
         const int gy = y0 - 1 + (pyx[g] & 0xff), gx = x0 - 1 + (pyx[g] >> 8);
-        const bool ok = live && c0 < p.K && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const bool ok = live && c0 < p.K && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W &&
+                        !(DBG && (p.debug & 1));
         const int e = (img * p.H + y0 - 1) * p.W + x0 - 1 + poff[g];
         const T* src = ok ? src0 + (long)e * cs : zero;
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + (oct * NG + g) * 1024), 16, 0, 0);
@@ -991,41 +991,29 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
     }
 
     unsigned char* scr = smem + NBUF * A_BYTES + wave * G::SCR;
-    float* xch = reinterpret_cast<float*>(smem + NBUF * A_BYTES + G::NW * G::SCR);
-    const int tiles_y16 = (p.H + 15) / 16;
-    int cur = 0, it = 0;
+    // per-lane store constants: the read-back lane owns 8 channels (cv) of pixel (lane >> 2) of a 16-pixel row
+    const int s_px = lane >> 2, s_nn = wn * 32 + (lane & 3) * 8;
+    T* const s_dst = s_nn < p.N0 ? out0 + s_nn : out1 + (s_nn - p.N0);
+    const int s_stride = s_nn < p.N0 ? p.N0 : p.N1;
+    int s_x[2];  // pixel column of the lane's pixel in tile rows 2s (half 0) and 2s + 1 (half 1: rotated sub-tile rows)
+    s_x[0] = sub_px<MODE>(s_px);
+    s_x[1] = sub_px<MODE>(16 + s_px);
+
+    // BatchNorm partial statistics: accumulated in registers over ALL tiles of this workgroup (lane = channel),
+    // one row per (workgroup, wm) written at the end -- see hipseg_conv_stats_rows().
+    float ssum = 0.f, ssq = 0.f;
+    int cur = 0;
     int hist = 0;                // bit k: the tile k+1 iterations back was interior (issued all its stores)
-    size_t pend_row = 0;         // NB == 1: statistics row of the previous tile, written after the next barrier
-    bool pend = false;
-    for (; cc.tile < total_tiles; advance(cc), ++it) {
+    for (; cc.tile < total_tiles; advance(cc)) {
         // Counted wait for this tile's pieces.  VMEM ops retire in issue order; per wave the ops younger than
-        // P(tile k) are: S(k-2) [+ statistics stores], P(k+1), S(k-1) [+ statistics stores] (and, NB == 1, the
-        // paired statistics stores X(k-2) of the even waves).  The count is exact only when both previous tiles
-        // were interior (every predicated store really issued); otherwise, and for the first two tiles, drain.
-        if (hist == 3) {
-            constexpr int BASE = (DIST - 1) * NAW + DIST * NST;
-            if (!p.stats)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-            else if (NB == 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + DIST * 2) : "memory");
-            else if (!(wave & 1))
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + (DIST - 1) * 2) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-        } else {
+        // P(tile k) are: S(k-2), P(k+1), S(k-1).  The count is exact only when both previous tiles were interior
+        // (every predicated store really issued); otherwise, and for the first two tiles, drain.
+        if (hist == 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NAW + DIST * NST) : "memory");
+        else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (NB == 1 && p.stats && pend && !(wave & 1)) {
-            // wave pair (wm, wm + 1) = one 64-pixel statistics group: the odd wave parked its partial sums
-            const float* mine = xch + (((it - 1) & 1) * G::NW + wave) * 64;
-            const float* other = mine + 64;
-            if (h == 0) {
-                p.stats[(pend_row * 2 + 0) * p.N + n] = mine[r] + other[r];
-                p.stats[(pend_row * 2 + 1) * p.N + n] = mine[32 + r] + other[32 + r];
-            }
-        }
         const bool more = cn.tile < total_tiles;
         unsigned char* nbase = smem + ((cur + DIST) % NBUF) * A_BYTES;
         const int ny0 = cn.ty * G::THS, nx0 = cn.tx * TW, nimg = cn.img;
@@ -1053,6 +1041,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
         for (int q = 0; q < NQ; ++q) {
             if (q + DEPTH - 1 < NQ) fetch((q + DEPTH - 1) % DEPTH, q + DEPTH - 1);
             if (q % PSTEP == 0 && q / PSTEP < NAW) piece(q / PSTEP, nbase, nimg, ny0, nx0, more);
+            if (DBG && (p.debug & 4)) continue;  // ablation build only
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int ai = MT == 1 ? (q & 1) : i;
@@ -1067,73 +1056,64 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
             for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
         }
 
-        // ---- wave-private epilogue
+        // ---- wave-private epilogue: bias, statistics, bf16 transpose through a 1-KiB LDS tile (16 px x 32 ch),
+        // 16-byte stores.  Interior tiles (all of the U-Net's) take the branch-free path.
         const int y0 = cc.ty * G::THS, x0 = cc.tx * TW, img = cc.img;
-        float ssum = 0.f, ssq = 0.f;
-        const bool interior = y0 + G::THS <= p.H && x0 + TW <= p.W;
+        const bool interior = y0 + G::THS <= p.H && x0 + TW <= p.W && !(DBG && (p.debug & 24));
+        const int tbase = (img * p.H + y0) * p.W + x0;  // first pixel of the tile
+        if (DBG && (p.debug & 8)) {
+            hist = 0;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int yb = y0 + 2 * (wm * MT + i);
+            const int yr = 2 * (wm * MT + i);  // first of the sub-tile's two tile rows
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+                if (interior) {
 #pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const int e = half * 8 + e8;
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
-                    const float v = acc[i][e] + bv;
-                    reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
-                    if (yb + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int e = half * 8 + e8;
+                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
+                        const float v = acc[i][e] + bv;
+                        reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
                         ssum += v;
                         ssq += v * v;
+                    }
+                } else {
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int e = half * 8 + e8;
+                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = acc[i][e] + bv;
+                        reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
+                        if (y0 + yr + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
+                            ssum += v;
+                            ssq += v * v;
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 {
-                    const int px = lane >> 2, cv = lane & 3;
-                    const bf16x8 o = *reinterpret_cast<const bf16x8*>(scr + (px * 32 + cv * 8) * 2);
-                    const int y = yb + half, x = x0 + sub_px<MODE>(half * 16 + px);
-                    const int nn = wn * 32 + cv * 8;
-                    if (y < p.H && x < p.W) {
-                        const long opix = ((long)img * p.H + y) * p.W + x;
-                        T* dst = (nn < p.N0) ? out0 + opix * p.N0 + nn : out1 + opix * p.N1 + (nn - p.N0);
-                        *reinterpret_cast<bf16x8*>(dst) = o;
-                    }
+                    const bf16x8 o = *reinterpret_cast<const bf16x8*>(scr + (s_px * 32 + (lane & 3) * 8) * 2);
+                    const int rel = (yr + half) * p.W + s_x[half];
+                    if (interior || (y0 + yr + half < p.H && x0 + s_x[half] < p.W && !(DBG && (p.debug & 16))))
+                        *reinterpret_cast<bf16x8*>(s_dst + (long)(tbase + rel) * s_stride) = o;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (p.stats) {
-            const float S = ssum + __shfl_xor(ssum, 32, 64);
-            const float Q = ssq + __shfl_xor(ssq, 32, 64);
-            // 64-pixel statistics group of this wave inside the 16x16 tile grid (see conv_epilogue)
-            const int Gi = (y0 & 15) / 4 + (NB == 2 ? wm : wm / 2);
-            const size_t row = (((size_t)img * tiles_y16 + y0 / 16) * p.tiles_x + x0 / 16) * 4 + Gi;
-            if (NB == 2) {
-                if (h == 0) {
-                    p.stats[(row * 2 + 0) * p.N + n] = S;
-                    p.stats[(row * 2 + 1) * p.N + n] = Q;
-                }
-            } else {
-                float* slot = xch + ((it & 1) * G::NW + wave) * 64;
-                if (h == 0) {
-                    slot[r] = S;
-                    slot[32 + r] = Q;
-                }
-                pend_row = row;
-                pend = true;
-            }
-        }
         hist = ((hist << 1) | (interior ? 1 : 0)) & 3;
     }
-    if (NB == 1 && p.stats && pend) {
-        __syncthreads();
-        if (!(wave & 1) && h == 0) {
-            const float* mine = xch + (((it - 1) & 1) * G::NW + wave) * 64;
-            const float* other = mine + 64;
-            p.stats[(pend_row * 2 + 0) * p.N + n] = mine[r] + other[r];
-            p.stats[(pend_row * 2 + 1) * p.N + n] = mine[32 + r] + other[32 + r];
+    if (p.stats) {
+        const float S = ssum + __shfl_xor(ssum, 32, 64);
+        const float Q = ssq + __shfl_xor(ssq, 32, 64);
+        const size_t row = (size_t)blockIdx.x * G::WM + wm;
+        if (h == 0) {
+            p.stats[(row * 2 + 0) * p.N + n] = S;
+            p.stats[(row * 2 + 1) * p.N + n] = Q;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1144,15 +1124,21 @@ int launch_wstat(const ConvArgs& a, hipStream_t s) {
     typedef WsGeo<KCH, NB> G;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
         attr_set = true;
     }
-    // whole 16-row tiles: every statistics row of the 16x16 tile grid gets written (zeros outside the image)
-    const int tiles_y8 = 2 * cdiv(a.H, 16);
+    const int tiles_y8 = cdiv(a.H, G::THS);
     const long total = (long)a.B * a.tiles_x * tiles_y8;
-    const long grid = total < 2 * a.ncu ? total : 2 * a.ncu;
-    hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB>), dim3((unsigned)grid), dim3(256), G::LDS, s, a, (int)total, tiles_y8);
+    const long grid = 2 * a.ncu;  // wstat_grid(): total >= 4 * ncu
+    if (a.debug)
+        hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a, (int)total,
+                           tiles_y8);
+    else
+        hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, false>), dim3((unsigned)grid), dim3(256), G::LDS, s, a,
+                           (int)total, tiles_y8);
     HS_LAUNCH_CHECK("conv3_wstat");
     return HIPSEG_OK;
 }
@@ -1264,6 +1250,20 @@ int launch_mode(const ConvArgs& a, int mode, int bn, hipStream_t s) {
     }
 }
 
+// Shape test for the weights-stationary kernel (conv3_wstat_kernel): <= 64-channel 3x3 layers with enough 128-pixel
+// tiles for two persistent workgroups per CU.  Returns the launch grid (0 = not applicable).
+int wstat_grid(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W) {
+    static const bool off = getenv("HIPSEG_NO_WSTAT") != nullptr || getenv("HIPSEG_NO_DMA") != nullptr;
+    if (off || dtype != HIPSEG_BF16 || mode != HIPSEG_CONV3) return 0;
+    if (C0 % 8 || C1 % 8 || N0 % 8 || N1 % 8) return 0;
+    const int K = C0 + C1, N = N0 + N1, Kp = (K + 15) / 16 * 16;
+    if (!(N == 32 || N == 64) || !(Kp == 32 || Kp == 64)) return 0;
+    const long total = (long)B * cdiv(W, TW) * cdiv(H, 8);
+    const int ncu = 256;
+    if (total < 4 * ncu) return 0;
+    return 2 * ncu;
+}
+
 int bn_for(int N) {
     static const int bn_max = getenv("HIPSEG_BN_MAX") ? atoi(getenv("HIPSEG_BN_MAX")) : 128;  // tuning experiments
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
@@ -1282,6 +1282,12 @@ extern "C" int hipseg_npad(int N) {
 }
 // rows of the statistics workspace: one per 64 output pixels (4 per 16x16 tile)
 extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return 4 * B * cdiv(H, TH) * cdiv(W, TW); }
+// rows hipseg_conv_igemm() writes for this call (<= hipseg_conv_mtiles(), which sizes the workspace)
+extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W) {
+    const int g = wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W);
+    if (g) return g * (N0 + N1 == 64 ? 2 : 4);  // one row per (workgroup, pixel-row wave group)
+    return hipseg_conv_mtiles(B, H, W);
+}
 
 extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
                                  const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
@@ -1341,11 +1347,7 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             if (mode == HIPSEG_CONV3 && H >= 32 && !no_tall)
                 return bn == 64 ? launch_pers<HIPSEG_CONV3, 64, 32>(a, s) : launch_pers<HIPSEG_CONV3, 32, 32>(a, s);
         }
-        // <= 64-channel 3x3 layers with enough 128-pixel tiles for two persistent workgroups per CU: weights-stationary
-        static const bool no_wstat = getenv("HIPSEG_NO_WSTAT") != nullptr;
-        if (mode == HIPSEG_CONV3 && a.vec_ok && !no_dma && !no_wstat && !dbg && N0 % 8 == 0 && N1 % 8 == 0 &&
-            a.N == a.Np && (a.Np == 32 || a.Np == 64) && (a.Kp == 32 || a.Kp == 64) &&
-            (long)B * a.tiles_x * 2 * cdiv(H, 16) >= 4 * a.ncu) {
+        if (wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W)) {
             if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
             return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
         }

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "hipseg_kpad": (I, [I, I]),
     "hipseg_npad": (I, [I]),
     "hipseg_conv_mtiles": (I, [I, I, I]),
+    "hipseg_conv_stats_rows": (I, [I, I, I, I, I, I, I, I, I]),
     "hipseg_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
     "hipseg_pack_conv_weight_both": (I, [P, P, P, I, I, I, I, P]),
     "hipseg_pack_convT_weight": (I, [P, P, I, I, I, I, P]),
@@ -64,7 +65,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a geometry answer, not a status code
-_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_bn_bwd_blocks",
+_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
          "hipseg_wgrad_workspace_elems", "hipseg_last_error"}
 

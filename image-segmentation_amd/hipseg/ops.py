@@ -178,10 +178,10 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     bn = _BN(cout, dev)
     s = _stream()
     if train:
-        mt = L.conv_mtiles(B, H, W)
-        stats = _f32(mt * 2 * cout, dev)
+        stats = _f32(L.conv_mtiles(B, H, W) * 2 * cout, dev)
         igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, stats, B, H, W)
-        L.bn_finalize(ptr(stats), mt, cout, float(B * H * W), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm), ptr(rv),
+        rows = L.conv_stats_rows(dt, L.CONV3, c0, c1, cout, 0, B, H, W)
+        L.bn_finalize(ptr(stats), rows, cout, float(B * H * W), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm), ptr(rv),
                       ptr(nbt), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), s)
     else:
         igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, None, B, H, W)

@@ -51,7 +51,12 @@ int hipseg_abi_version(void);
 int hipseg_kpad(int K, int dtype);
 int hipseg_npad(int N);
 /* rows of the BatchNorm statistics workspace for a (B,H,W) pixel grid (one per 64 output pixels) */
+/* UPPER BOUND of the rows of the BatchNorm statistics workspace for a (B,H,W) pixel grid (one per 64 output
+ * pixels): sizes the allocation */
 int hipseg_conv_mtiles(int B, int H, int W);
+/* rows hipseg_conv_igemm() actually WRITES for a call with these arguments (the persistent kernels write one
+ * row per workgroup wave-group instead of one per 64 pixels); pass it to hipseg_bn_finalize() */
+int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
 
 /* Conv2d weight (Cout,Cin,kh,kw) fp32 -> packed [tap][Kp/G][Np][G] in `dtype`.
  * transpose=0: forward operand      (K = Cin, N = Cout, tap = ky*kw+kx)
@@ -80,8 +85,9 @@ int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int Cin, int C
  *             NULL.  Used by the data-gradient of a dual-source conv.
  *   (H, W)  : the GEMM-M pixel grid = output grid for CONV3/CONV1/CONV2S2 (input grid is
  *             2H x 2W for CONV2S2), INPUT grid for CONVT (output is 2H x 2W, N0 = Cout).
- *   stats   : NULL or float[hipseg_conv_mtiles()][2][N]: per-64-pixel column sums and sums of squares of
- *             the fp32 results (the BatchNorm batch-statistics partials, fused epilogue).
+ *   stats   : NULL or float[hipseg_conv_mtiles()][2][N]: partial column sums and sums of squares of the fp32
+ *             results (the BatchNorm batch-statistics partials, fused epilogue); rows [0, hipseg_conv_stats_rows())
+ *             are written, each output pixel is counted in exactly one of them.
  * replaces: aten::conv2d 3x3/1x1 (processing_blocks.py:43,46), its dgrad, and
  *           aten::conv_transpose2d fwd/dgrad (processing_blocks.py:102,106). */
 int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,

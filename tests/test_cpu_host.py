@@ -52,6 +52,13 @@ def test_host_geometry_functions(L):
     assert L.npad(32) == 32 and L.npad(64) == 64 and L.npad(65) == 128 and L.npad(512) == 512 and L.npad(3) == 32
     assert L.conv_mtiles(16, 256, 256) == 4 * 16 * 16 * 16
     assert L.conv_mtiles(1, 28, 28) == 16
+    # rows actually written: the per-64-pixel grid, except for the persistent weights-stationary kernel
+    # (bf16 3x3, <= 64 channels, >= 1024 tiles of 8x16 pixels): one row per (workgroup, wave row group)
+    assert L.conv_stats_rows(L.F32, L.CONV3, 64, 0, 64, 0, 16, 256, 256) == L.conv_mtiles(16, 256, 256)
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 128, 0, 16, 256, 256) == L.conv_mtiles(16, 256, 256)
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 64, 0, 1, 32, 32) == L.conv_mtiles(1, 32, 32)
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 64, 0, 16, 256, 256) == 512 * 2
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 32, 32, 32, 0, 16, 256, 256) == 512 * 4
     assert L.wgrad_workspace_elems(L.CONV3, 64, 64, 16, 256, 256) > 0
     assert L.loss_blocks(10) == 1 and L.loss_blocks(10 ** 9) == 1024
     assert L.bn_bwd_blocks(16, 256, 256, 64, L.BF16, 0) >= 1

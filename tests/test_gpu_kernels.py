@@ -100,7 +100,9 @@ def test_conv3_fwd_stats(hs, prec, td, dt, case):
                  ops.ptr(stats), B, H, W, s)
     torch.cuda.synchronize()
     check(out, want, td, what="conv3 fwd")
-    st = stats.cpu().double().sum(0)
+    rows = L.conv_stats_rows(dt, L.CONV3, C0, C1, Cout, 0, B, H, W)
+    assert 0 < rows <= mt
+    st = stats[:rows].cpu().double().sum(0)
     ssum = want.double().sum((0, 2, 3))
     ssq = (want.double() ** 2).sum((0, 2, 3))
     n = B * H * W
