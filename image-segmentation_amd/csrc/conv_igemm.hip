@@ -18,6 +18,10 @@
 
 #include "common.h"
 
+#ifndef IGEMM_PPT
+#define IGEMM_PPT 1
+#endif
+
 namespace {
 
 constexpr int TH = 16, TW = 16, BM = TH * TW;
@@ -515,7 +519,10 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
         }
     };
     constexpr int NPCW = NAW + NBW;                 // pieces per wave per chunk
-    constexpr int PPT = (NPCW + NT - 1) / NT;       // pieces issued per tap
+    // pieces issued per tap: at least IGEMM_PPT, so that a chunk's pieces all go out in its FIRST taps and have the
+    // rest of the chunk's MFMA time to land (spread evenly, the last piece is issued just before the barrier that
+    // waits for it)
+    constexpr int PPT = (NPCW + NT - 1) / NT > IGEMM_PPT || NT == 1 ? (NPCW + NT - 1) / NT : IGEMM_PPT;
 
     f32x16 acc[MT][NTL];
 #pragma unroll
