@@ -90,6 +90,61 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ w
     }
 }
 
+// One launch for ALL conv / ConvT weights of a model (blockIdx.y = descriptor): the per-layer pack launches are
+// ~5-7 us latency-bound helpers, ~24 of them per U-Net step.
+struct PackDesc {
+    const float* w;
+    void* wp;
+    void* wpt;
+    int kind;  // 0: Conv2d (Cout,Cin,ks,ks) -> forward + data-gradient operands; 1: ConvTranspose2d (Cin,Cout,2,2)
+    int Cout, Cin, ks;
+    int Kp0, Np0, Kp1, Np1;
+    long total0, total1;
+};
+
+template <typename T>
+__global__ void pack_batch_kernel(const PackDesc* __restrict__ descs, int G) {
+    const PackDesc d = descs[blockIdx.y];
+    const float* __restrict__ w = d.w;
+    T* __restrict__ wp = reinterpret_cast<T*>(d.wp);
+    T* __restrict__ wpt = reinterpret_cast<T*>(d.wpt);
+    const long total = d.total0 > d.total1 ? d.total0 : d.total1;
+    const int ks = d.ks, Cout = d.Cout, Cin = d.Cin;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < d.total0) {
+            const int g = (int)(idx % G);
+            const int n = (int)((idx / G) % d.Np0);
+            const int kg = (int)((idx / ((long)G * d.Np0)) % (d.Kp0 / G));
+            const int tap = (int)(idx / ((long)d.Kp0 * d.Np0));
+            const int k = kg * G + g;
+            float v = 0.f;
+            if (d.kind == 0) {  // K = Cin, N = Cout
+                const int ky = tap / ks, kx = tap % ks;
+                if (k < Cin && n < Cout) v = w[(((long)n * Cin + k) * ks + ky) * ks + kx];
+            } else if (k < Cin && n < 4 * Cout) {  // ConvT forward: 1 tap, K = Cin, N = 4*Cout, n = ab*Cout + co
+                const int ab = n / Cout, co = n % Cout;
+                v = w[((long)k * Cout + co) * 4 + ab];
+            }
+            wp[idx] = (T)v;
+        }
+        if (idx < d.total1) {
+            const int g = (int)(idx % G);
+            const int n = (int)((idx / G) % d.Np1);
+            const int kg = (int)((idx / ((long)G * d.Np1)) % (d.Kp1 / G));
+            const int tap = (int)(idx / ((long)d.Kp1 * d.Np1));
+            const int k = kg * G + g;
+            float v = 0.f;
+            if (d.kind == 0) {  // K = Cout, N = Cin, taps flipped
+                const int ky = tap / ks, kx = tap % ks;
+                if (k < Cout && n < Cin) v = w[(((long)k * Cin + n) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+            } else if (k < Cout && n < Cin) {  // ConvT data gradient: tap = ab, K = Cout, N = Cin
+                v = w[((long)n * Cout + k) * 4 + tap];
+            }
+            wpt[idx] = (T)v;
+        }
+    }
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -149,5 +204,53 @@ extern "C" int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int
         hipLaunchKernelGGL(pack_convT_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)wp, Cin, Cout,
                            transpose, Kp, Np, G, total);
     HS_LAUNCH_CHECK("pack_convT_weight");
+    return HIPSEG_OK;
+}
+
+extern "C" size_t hipseg_pack_desc_size(void) { return sizeof(PackDesc); }
+
+extern "C" int hipseg_pack_desc_fill(void* host_descs, int index, const float* w, void* wp, void* wpt, int kind,
+                                     int dtype, int Cout, int Cin, int ksize) {
+    HS_REQUIRE(host_descs && index >= 0 && w && wp && wpt && Cout > 0 && Cin > 0, "pack_desc_fill: bad arguments");
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_desc_fill: bad dtype");
+    HS_REQUIRE((kind == 0 && (ksize == 1 || ksize == 3)) || (kind == 1 && ksize == 2), "pack_desc_fill: bad kind/ksize");
+    PackDesc& d = reinterpret_cast<PackDesc*>(host_descs)[index];
+    d.w = w;
+    d.wp = wp;
+    d.wpt = wpt;
+    d.kind = kind;
+    d.Cout = Cout;
+    d.Cin = Cin;
+    d.ks = ksize;
+    if (kind == 0) {
+        d.Kp0 = hipseg_kpad(Cin, dtype);
+        d.Np0 = hipseg_npad(Cout);
+        d.Kp1 = hipseg_kpad(Cout, dtype);
+        d.Np1 = hipseg_npad(Cin);
+        d.total0 = (long)ksize * ksize * d.Kp0 * d.Np0;
+        d.total1 = (long)ksize * ksize * d.Kp1 * d.Np1;
+    } else {
+        d.Kp0 = hipseg_kpad(Cin, dtype);
+        d.Np0 = hipseg_npad(4 * Cout);
+        d.Kp1 = hipseg_kpad(Cout, dtype);
+        d.Np1 = hipseg_npad(Cin);
+        d.total0 = (long)d.Kp0 * d.Np0;
+        d.total1 = (long)4 * d.Kp1 * d.Np1;
+    }
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_pack_batch(const void* dev_descs, int n, int dtype, long max_total, hipseg_stream_t stream) {
+    HS_REQUIRE(dev_descs && n > 0 && max_total > 0, "pack_batch: bad arguments");
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_batch: bad dtype");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    long gx = (max_total + 255) / 256;
+    if (gx > 256) gx = 256;
+    const dim3 grid((unsigned)gx, (unsigned)n);
+    if (dtype == HIPSEG_BF16)
+        hipLaunchKernelGGL(pack_batch_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs), 8);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs), 1);
+    HS_LAUNCH_CHECK("pack_batch");
     return HIPSEG_OK;
 }

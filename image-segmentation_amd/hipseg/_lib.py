@@ -34,6 +34,9 @@ PROTOTYPES = {
     "hipseg_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
     "hipseg_pack_conv_weight_both": (I, [P, P, P, I, I, I, I, P]),
     "hipseg_pack_convT_weight": (I, [P, P, I, I, I, I, P]),
+    "hipseg_pack_desc_size": (c_size_t, []),
+    "hipseg_pack_desc_fill": (I, [P, I, P, P, P, I, I, I, I, I]),
+    "hipseg_pack_batch": (I, [P, I, I, L, P]),
     "hipseg_conv_igemm": (I, [I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
     "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),
@@ -67,7 +70,7 @@ PROTOTYPES = {
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
-         "hipseg_wgrad_workspace_elems", "hipseg_last_error"}
+         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size"}
 
 
 def _load():

@@ -40,6 +40,8 @@ class _UNetBase(nn.Module):
         div = 2 ** len(self._enc)
         if x.dim() != 4 or x.shape[2] % div or x.shape[3] % div:
             raise ValueError(f"input must be (B,C,H,W) with H, W divisible by {div}; got {tuple(x.shape)}")
+        ops._require_gpu(x)
+        ops.prepack(self, ops.precision())  # all conv / ConvT operands of this step, one launch
         h = _stem(self.input, x)
         skips = [h]
         for k in range(1, len(self._enc) + 1):

@@ -76,6 +76,18 @@ int hipseg_pack_conv_weight_both(const float* w, void* wp, void* wpt, int dtype,
 int hipseg_pack_convT_weight(const float* w, void* wp, int dtype, int Cin, int Cout, int transpose,
                              hipseg_stream_t stream);
 
+/* All conv / ConvT weights of a model in ONE launch (the per-layer calls above are latency-bound helpers).
+ * A descriptor table is filled on the host (hipseg_pack_desc_fill into a buffer of n * hipseg_pack_desc_size()
+ * bytes), copied to the device by the caller, and replayed every step:
+ *   kind 0: Conv2d weight (Cout,Cin,k,k) -> wp = forward operand, wpt = data-gradient operand
+ *           (= hipseg_pack_conv_weight_both);  kind 1: ConvTranspose2d weight (Cin,Cout,2,2) -> wp = forward
+ *           operand, wpt = data-gradient operand (= hipseg_pack_convT_weight transpose 0 / 1).
+ * max_total = the largest packed operand in elements (sizes the grid). */
+size_t hipseg_pack_desc_size(void);
+int hipseg_pack_desc_fill(void* host_descs, int index, const float* w, void* wp, void* wpt, int kind, int dtype,
+                          int Cout, int Cin, int ksize);
+int hipseg_pack_batch(const void* dev_descs, int n, int dtype, long max_total, hipseg_stream_t stream);
+
 /* ---- implicit-GEMM convolution (MFMA) ---------------------------------------------
  * out[n,y,x,:] = bias + sum_taps sum_c in[n, tap(y,x), c] * W[tap][c][:]
  *   in0/in1 : up to two NHWC sources concatenated along channels (C0 + C1 = K); in1 may be

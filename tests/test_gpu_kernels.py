@@ -317,3 +317,29 @@ def test_losses_and_confusion(hs, golden):
     want0 = R.hybrid_loss_binary(bl, z)
     got0 = ops.BceDiceFn.apply(bl.cuda(), z.cuda())
     assert abs(float(got0) - float(want0)) < 5e-6
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+def test_pack_batch_matches_per_layer_pack(hs, prec, td, dt):
+    """hipseg_pack_batch (all weights of a module, one launch) == the per-layer pack entry points, bit for bit."""
+    L, ops = hs.L, hs.ops
+    net = torch.nn.Sequential(torch.nn.Conv2d(24, 40, 3, padding=1), torch.nn.ConvTranspose2d(64, 32, 2, stride=2),
+                              torch.nn.Conv2d(64, 64, 3, padding=1), torch.nn.Conv2d(3, 32, 1),
+                              torch.nn.ConvTranspose2d(12, 6, 2, stride=2)).cuda()
+    ops._PACKED.clear()
+    want = []
+    for m in net:
+        if isinstance(m, torch.nn.ConvTranspose2d):
+            want.append((ops._pack_convT(m.weight, dt, False), ops._pack_convT(m.weight, dt, True)))
+        elif m.kernel_size == (3, 3):
+            want.append(ops._pack_conv_both(m.weight, dt))
+    ops.prepack(net, prec)
+    torch.cuda.synchronize()
+    got = [ops._cached_pack(m.weight, dt) for m in net if not (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1))]
+    assert len(got) == len(want) == 4 and all(g is not None for g in got)
+    for (gp, gt), (wp, wt) in zip(got, want):
+        assert torch.equal(gp.float(), wp.float()) and torch.equal(gt.float(), wt.float())
+    # a weight modified in place after prepack is no longer served from the cache
+    with torch.no_grad():
+        net[0].weight.add_(1.0)
+    assert ops._cached_pack(net[0].weight, dt) is None
