@@ -75,6 +75,15 @@ def cpu_baseline(args):
                       f"(oracle/torch_ref.OracleTrainer, torch {torch.__version__} CPU, {cores} threads), 1 warm-up"}
 
 
+def _config_index(args, world):
+    """BASELINE.json config this run corresponds to (1: UNet 256 b16, 2: LargeUNet 512 b8, 3: UNet DDP, 4: ClipUnet)."""
+    if args.model == "LargeUNet":
+        return 2
+    if args.model == "ClipUnet":
+        return 4
+    return 3 if world > 1 else 1
+
+
 def main():
     args = parse()
     import torch
@@ -210,7 +219,7 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} 3x{args.size}x{args.size} train step (fwd + CE + bwd + GradScaler/Adam"
                                f"{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch {args.batch}/GPU, "
-                               f"BASELINE.json configs[1]",
+                               f"BASELINE.json configs[{_config_index(args, world)}]",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}",
                    "loop": ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager RCCL all-reduce + hipgraph(optimizer)")
