@@ -74,7 +74,13 @@ struct ConvArgs {
                   // workgroups that share a CU so one's epilogue stores overlap the other's MFMA phase
     int ncu;
     int debug;  // ablation bits (HIPSEG_IGEMM_DEBUG): 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip epilogue
+    int xcd;    // XCD-aware workgroup order: 0 off, else grid / 8 (see xcd_block)
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Give every XCD a CONTIGUOUS run of
+// logical workgroup ids instead, so the N-tile workgroups of one pixel tile (same halo tile) and neighbouring
+// pixel tiles (shared halo rows) hit the same L2 (guide T1; needs grid % 8 == 0).
+__device__ __forceinline__ int xcd_block(int bid, int cpx) { return cpx ? (bid & 7) * cpx + (bid >> 3) : bid; }
 
 // Wave grid of a workgroup.  The generic kernel runs 4 waves; the DMA kernel runs 8 waves (two per SIMD, so
 // one wave's LDS / barrier waits hide behind the other's MFMAs) on the 256x128 tile.
@@ -260,8 +266,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int ntile = blockIdx.x % p.ntn;
-    const int mtile = blockIdx.x / p.ntn;
+    const int bid = xcd_block(blockIdx.x, p.xcd);
+    const int ntile = bid % p.ntn;
+    const int mtile = bid / p.ntn;
     const int tx = mtile % p.tiles_x;
     const int ty = (mtile / p.tiles_x) % p.tiles_y;
     const int img = mtile / (p.tiles_x * p.tiles_y);
@@ -455,8 +462,9 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int ntile = blockIdx.x % p.ntn;
-    const int mtile = blockIdx.x / p.ntn;
+    const int bid = xcd_block(blockIdx.x, p.xcd);
+    const int ntile = bid % p.ntn;
+    const int mtile = bid / p.ntn;
     const int tx = mtile % p.tiles_x;
     const int ty = (mtile / p.tiles_x) % p.tiles_y;
     const int img = mtile / (p.tiles_x * p.tiles_y);
@@ -1205,6 +1213,8 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
         attr_set = true;
     }
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
+    a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
     hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN, THT>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm_dma");
     return HIPSEG_OK;
@@ -1338,6 +1348,7 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     static const int stg = getenv("HIPSEG_STAGGER") ? atoi(getenv("HIPSEG_STAGGER")) : 0;
     a.stagger = stg;
     a.ncu = 256;
+    a.xcd = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only

@@ -54,7 +54,13 @@ struct WgArgs {
     // dY rows 2y, 2y+1 (each row holds (b, co) = 2*Cout contiguous values at column 2x).  0 = plain tensor.
     int convt_cout;
     int debug;  // ablation bits (HIPSEG_WGRAD_DEBUG): 1 skip P staging, 2 skip Q staging, 4 skip MFMA, 8 skip slab store
+    int xcd;    // XCD-aware workgroup order: 0 off, else grid / 8 (see xcd_block)
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Give every XCD a CONTIGUOUS run of
+// logical workgroup ids instead, so the (u-tile, v-tile) workgroups of one pixel split -- which read the same
+// pixels' channel slices, each slice UT or VT times -- share an L2 (guide T1; needs grid % 8 == 0).
+__device__ __forceinline__ int xcd_block(int bid, int cpx) { return cpx ? (bid & 7) * cpx + (bid >> 3) : bid; }
 
 // element offset of channel c (first of an aligned 8/4-vector) of P pixel (img, gy, gx)
 __device__ __forceinline__ long p_offset(const WgArgs& a, int img, int gy, int gx, int c, const void*& base) {
@@ -91,9 +97,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int wu = wave / WV, wv = wave % WV;
 
-    const int vt = blockIdx.x % a.VT;
-    const int ut = (blockIdx.x / a.VT) % a.UT;
-    const int s = blockIdx.x / (a.VT * a.UT);
+    const int bid = xcd_block(blockIdx.x, a.xcd);
+    const int vt = bid % a.VT;
+    const int ut = (bid / a.VT) % a.UT;
+    const int s = bid / (a.VT * a.UT);
     const int u0 = ut * UC, v0 = vt * VC;
 
     const T* p0 = reinterpret_cast<const T*>(a.p0);
@@ -286,9 +293,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int uv = wave % (UB * VB), wu = uv % UB, wv = uv / UB, kh = wave / (UB * VB);
-    const int vt = blockIdx.x % a.VT;
-    const int ut = (blockIdx.x / a.VT) % a.UT;
-    const int s = blockIdx.x / (a.VT * a.UT);
+    const int bid = xcd_block(blockIdx.x, a.xcd);
+    const int vt = bid % a.VT;
+    const int ut = (bid / a.VT) % a.UT;
+    const int s = bid / (a.VT * a.UT);
     const int u0 = ut * PCH, v0 = vt * QCH;
     const char* zero = reinterpret_cast<const char*>(&g_wg_zero16);
     unsigned char* sink = smem + NBUF * BUF;
@@ -694,6 +702,9 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
     static const int dbg = getenv("HIPSEG_WGRAD_DEBUG") ? atoi(getenv("HIPSEG_WGRAD_DEBUG")) : 0;
     a.debug = dbg;
+    static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
+    const int nwg = pl.S * pl.UT * pl.VT;
+    a.xcd = (!no_xcd && pl.UT * pl.VT > 1 && nwg % 8 == 0) ? nwg / 8 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)pl.NT * CU * CV;
     const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
