@@ -84,6 +84,26 @@ def _config_index(args, world):
     return 3 if world > 1 else 1
 
 
+# HBM traffic of the roofline kernel comes from committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share
+# a pass; PMC collection cannot run inside the timed bench): profiles/r01_pmc_traffic.json, made by
+# scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --loop eager`.
+_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": ("wgrad_dma_kernel<9,", "wgrad_reduce3_kernel", "colreduce_inplace_kernel"),
+                "conv_igemm<bf16,CONV3,BN128>": ("conv_igemm_dma_kernel<0, 128,",)}
+
+
+def _pmc_traffic(key, args):
+    """(average HBM bytes per launch of the roofline kernel, provenance) or (None, reason)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if (args.model, args.size, args.batch) != ("UNet", 256, 16) or key not in _PMC_KERNELS or not os.path.exists(path):
+        return None, "no PMC pass for this kernel/config"
+    ks = json.load(open(path))["kernels"]
+    main_pat = _PMC_KERNELS[key][0]
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(p in k for p in _PMC_KERNELS[key]))
+    n = sum(v["launches"] for k, v in ks.items() if main_pat in k)
+    return (round(tot / n), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)") \
+        if n else (None, "kernel not in the PMC pass")
+
+
 def main():
     args = parse()
     import torch
@@ -252,6 +272,7 @@ def main():
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                            "launches_per_step": dom[1][0] // nprof, "avg_launch_ms": round(dom[1][2] / dom[1][0], 5),
                            "flops_per_launch_avg": dom[1][1] / dom[1][0]}
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = _pmc_traffic(dom[0], args)
         out["kernels"] = kern
         out["mfma_kernels_ms_per_step"] = round(sum(v[2] for v in agg.values()) / nprof, 4)
 
