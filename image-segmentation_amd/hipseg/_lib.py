@@ -65,6 +65,7 @@ PROTOTYPES = {
     "hipseg_confusion": (I, [P, P, P, I, I, L, P]),
     "hipseg_nchw_to_nhwc": (I, [I, P, P, I, I, I, I, P]),
     "hipseg_nhwc_to_nchw": (I, [I, P, P, I, I, I, I, P]),
+    "hipseg_decode_records": (I, [P, P, P, P, P, I, I, I, P]),
 }
 
 # functions whose int return value is a geometry answer, not a status code

@@ -1,0 +1,40 @@
+"""Checkpoint exchange with the reference.
+
+The reference saves `model.state_dict()` of a `torch.compile`d (and, under DDP, wrapped) model, so keys carry the
+prefixes `_orig_mod.` and `module.` (models/model_wrappers.py:249,1047); its loaders strip `_orig_mod.` before
+`load_state_dict` (models/model_wrappers.py:323-332).  Our modules register the same names and shapes, so a
+reference checkpoint loads here -- and ours loads there -- once the wrapper prefixes are normalised."""
+from collections import OrderedDict
+
+import torch
+
+PREFIXES = ("_orig_mod.", "module.")
+
+
+def strip_wrapper_prefixes(state_dict):
+    """Remove every `_orig_mod.` / `module.` wrapper prefix occurrence (model_wrappers.py:326-329 uses
+    `k.replace("_orig_mod.", "")`, i.e. anywhere in the key; DDP adds `module.` in front)."""
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        nk = k
+        for p in PREFIXES:
+            nk = nk.replace(p, "")
+        if nk in out:
+            raise KeyError(f"hipseg.ckpt: keys collide after prefix removal: {k!r} -> {nk!r}")
+        out[nk] = v
+    return out
+
+
+def load_reference_checkpoint(model, path_or_state, strict=True):
+    """Load a reference-format checkpoint (path or state_dict) into one of our drop-in models.  Files are opened
+    with `weights_only=True` only (nothing from the file is executed)."""
+    sd = path_or_state
+    if not isinstance(sd, dict):
+        sd = torch.load(path_or_state, map_location="cpu", weights_only=True)
+    return model.load_state_dict(strip_wrapper_prefixes(sd), strict=strict)
+
+
+def reference_state_dict(model, compiled=False, ddp=False):
+    """Our state_dict under the key names the reference's wrappers would have produced."""
+    prefix = ("module." if ddp else "") + ("_orig_mod." if compiled else "")
+    return OrderedDict((prefix + k, v) for k, v in model.state_dict().items())

@@ -219,6 +219,16 @@ int hipseg_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H,
 int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W,
                         hipseg_stream_t stream);
 
+/* ---- dataset-record decode (the data format in front of the path) -----------------------------
+ * images: n records of H x W x 3 uint8 (HWC), masks: n records of H x W uint8 (38 = cat, 75 = dog, 255 = border).
+ * out_images: float32 (n,3,H,W) = byte / 255.0; out_masks: int64 (n,H,W) =
+ *   record has a cat pixel ? (m == 38) + (m == 255) : 2*(m == 75) + 2*(m == 255).
+ * cat_flags: int[n] workspace (per-record "any cat pixel").  H*W must be a multiple of 4.
+ * replaces: CustomImageDataset._deserialize_datapoint / _deserialize_numpy, customDatasets/datasets.py:92-135
+ * (the reference decodes one record at a time with numpy on the host; its records are 256 x 256). */
+int hipseg_decode_records(const uint8_t* images, const uint8_t* masks, float* out_images, int64_t* out_masks,
+                          int* cat_flags, int n, int H, int W, hipseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

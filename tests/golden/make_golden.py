@@ -231,8 +231,42 @@ def gen_losses():
     print("losses.npz", len(out))
 
 
+# ------------------------------------------------------------------ dataset-record decode
+def gen_records():
+    """Outputs of the reference's OWN `CustomImageDataset._deserialize_datapoint` (customDatasets/datasets.py:92-135)
+    on the synthetic records of oracle.records.make_records().  The class cannot be constructed offline (its
+    __init__ downloads the dataset), so the two decode methods are called on a bare instance."""
+    sys.modules.setdefault("scripts.dataset_downloader", MagicMock())
+    from customDatasets.datasets import CustomImageDataset  # reference
+    from oracle import records
+    images, masks = records.make_records()
+    ds = CustomImageDataset.__new__(CustomImageDataset)
+    out = {"mask_in": masks}
+    lut = np.full(256, np.nan, np.float32)
+    for i in range(images.shape[0]):
+        img, msk = ds._deserialize_datapoint({"image": images[i].tobytes(), "mask": masks[i].tobytes()})
+        img, msk = npy(img), npy(msk)
+        assert img.shape == (3, 256, 256) and img.dtype == np.float32 and msk.shape == (256, 256)
+        out[f"mask_out_{i}"] = msk.astype(np.uint8)          # values 0..2
+        out[f"mask_dtype_{i}"] = np.array(str(msk.dtype))
+        out[f"image_sum_{i}"] = img.astype(np.float64).sum((1, 2))  # per channel: pins the HWC -> CHW permutation
+        out[f"image_samples_{i}"] = img[:, ::37, ::41].copy()
+        # the image output is a function of the byte value alone: record the reference's value for every byte
+        hwc = np.transpose(img, (1, 2, 0))
+        lut[images[i].reshape(-1)] = hwc.reshape(-1)
+        assert np.array_equal(lut[images[i]], hwc)
+    assert not np.isnan(lut).any()
+    out["image_lut"] = lut
+    np.savez_compressed(os.path.join(HERE, "records.npz"), **out)
+    print("records.npz", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "records":  # regenerate one fixture file only
+        gen_records()
+        sys.exit(0)
     gen_blocks()
     gen_models()
     gen_clip()
     gen_losses()
+    gen_records()
