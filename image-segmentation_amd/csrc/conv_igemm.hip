@@ -131,6 +131,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     constexpr int VPR = TN / VEC;           // vectors per pixel row
     constexpr int NIT = 32 * VPR / 64;      // store iterations per sub-tile (>= 1)
     static_assert(32 * VPR % 64 == 0, "whole wave iterations");
+    // bf16 read-back: a lane takes 32 B (8 floats) as two ds_read_b128, i.e. only every second 16-byte slot per
+    // read, and the 16-lane groups of a b128 read span rows that alias in the 256-B bank window -> 2-way conflicts
+    // (measured: SQ_LDS_BANK_CONFLICT = 1/3 of the kernel's LDS cycles, all of it here).  XOR the 16-byte slot index
+    // with the parity of the row's bank window: the rows of a group then use complementary slots (conflict-free).
+    constexpr bool SWZ = VEC == 8 && (TN == 64 || TN == 32);
+    constexpr int RPW = SWZ ? 64 / TN : 1;  // tile rows per 256-B bank window
+    auto swz_col = [](int row, int col) { return SWZ ? ((((col >> 2) ^ ((row / RPW) & 1)) << 2) | (col & 3)) : col; };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -171,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const float v = acc[i][j][e] + bv[j];
-                tile[rr * TN + j * 32 + r] = v;
+                tile[rr * TN + swz_col(rr, j * 32 + r)] = v;
                 if (nok && yb + (rr >> 4) < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                     ssum[i / 2][j] += v;
                     ssq[i / 2][j] += v * v;
@@ -190,8 +197,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
                 const float* src = tile + rr * TN + cv * VEC;
                 if (vec_ok) {
                     typename VecOf<T>::type o;
+                    if (SWZ) {  // two 16-byte reads, their slots swapped on swizzled rows
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(tile + rr * TN + swz_col(rr, cv * VEC));
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(tile + rr * TN + swz_col(rr, cv * VEC + 4));
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) o[q] = (T)src[q];
+                        for (int q = 0; q < 4; ++q) {
+                            o[q] = (T)lo[q];
+                            o[4 + q] = (T)hi[q];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) o[q] = (T)src[q];
+                    }
                     T* dst;
                     if (MODE == HIPSEG_CONVT) {
                         const int ab = n / p.N0, co = n - ab * p.N0;
@@ -211,13 +228,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
                                 const int ab = nn / p.N0, co = nn - ab * p.N0;
                                 const long opix =
                                     ((long)img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-                                out0[opix * p.N0 + co] = (T)src[q];
+                                out0[opix * p.N0 + co] = (T)tile[rr * TN + swz_col(rr, cv * VEC + q)];
                             } else {
                                 const long opix = ((long)img * p.H + y) * p.W + x;
                                 if (nn < p.N0)
-                                    out0[opix * p.N0 + nn] = (T)src[q];
+                                    out0[opix * p.N0 + nn] = (T)tile[rr * TN + swz_col(rr, cv * VEC + q)];
                                 else
-                                    out1[opix * p.N1 + (nn - p.N0)] = (T)src[q];
+                                    out1[opix * p.N1 + (nn - p.N0)] = (T)tile[rr * TN + swz_col(rr, cv * VEC + q)];
                             }
                         }
                     }
