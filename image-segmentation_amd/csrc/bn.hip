@@ -259,40 +259,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 }
         }
     }
-    // reduce over pixel lanes: red[pl][2][C] would be large; do a two-step tree in LDS over pl.
-    // layout red[r][pl_slot][c] with at most 2048 floats per r -> process in rounds of R = 2048/C lanes
-    const int R = 2048 / C;  // >= 1 because C <= 2048
+    // reduce over the pixel lanes through LDS: red[r][pl][c] (PL * C <= 2048 floats per r for every vector width:
+    // one round), then COLUMN-parallel sums -- thread t adds column t over the PL rows in row order (the same
+    // order the former single-lane loop used, so results are bit-identical) with conflict-free consecutive reads.
     float* r1 = red;
     float* r2 = red + 2048;
-    float t1[V], t2[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) t1[e] = t2[e] = 0.f;
-    for (int base = 0; base < PL; base += R) {
-        __syncthreads();
-        if (pl >= base && pl < base + R && pl < PL) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                r1[(pl - base) * C + cg * V + e] = s1[e];
-                r2[(pl - base) * C + cg * V + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (pl == 0) {
-            const int lim = (PL - base) < R ? (PL - base) : R;
-            for (int j = 0; j < lim; ++j)
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    t1[e] += r1[j * C + cg * V + e];
-                    t2[e] += r2[j * C + cg * V + e];
-                }
-        }
-    }
-    if (pl == 0) {
+    if (pl < PL) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            partial[((size_t)blockIdx.x * 2 + 0) * C + cg * V + e] = t1[e];
-            partial[((size_t)blockIdx.x * 2 + 1) * C + cg * V + e] = t2[e];
+            r1[pl * C + cg * V + e] = s1[e];
+            r2[pl * C + cg * V + e] = s2[e];
         }
+    }
+    __syncthreads();
+    for (int col = tid; col < 2 * C; col += 256) {
+        const int arr = col / C, c = col - arr * C;
+        const float* rr = arr ? r2 : r1;
+        float acc = 0.f;
+        for (int j = 0; j < PL; ++j) acc += rr[j * C + c];
+        partial[((size_t)blockIdx.x * 2 + arr) * C + c] = acc;
     }
 }
 

@@ -54,20 +54,32 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? w[(cg * V + e) * Cin + ci] : 0.f;
         }
-        for (long i = i0; i < total; i += stride) {
-            const long p = i / CG;
-            const long n = p / HW, hw = p % HW;
-            float o[V];
+        constexpr int UNR = 4;  // pixels in flight per lane (the loop is latency-bound otherwise: 3 loads -> 1 store)
+        for (long i = i0; i < total; i += stride * UNR) {
+            float xv[UNR][MAXCIN];
+            long pp[UNR];
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = br[e];
+            for (int u = 0; u < UNR; ++u) {
+                const long iu = i + u * stride;
+                pp[u] = iu < total ? iu / CG : -1;
+                const long n = pp[u] / HW, hw = pp[u] % HW;
 #pragma unroll
-            for (int ci = 0; ci < MAXCIN; ++ci)
-                if (ci < Cin) {
-                    const float xv = x[(n * Cin + ci) * HW + hw];
+                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = (pp[u] >= 0 && ci < Cin) ? x[(n * Cin + ci) * HW + hw] : 0.f;
+            }
 #pragma unroll
-                    for (int e = 0; e < V; ++e) o[e] = fmaf(wr[ci][e], xv, o[e]);
-                }
-            stv<T, V>(y + p * Cout + cg * V, o);
+            for (int u = 0; u < UNR; ++u) {
+                if (pp[u] < 0) continue;
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = br[e];
+#pragma unroll
+                for (int ci = 0; ci < MAXCIN; ++ci)
+                    if (ci < Cin) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) o[e] = fmaf(wr[ci][e], xv[u][ci], o[e]);
+                    }
+                stv<T, V>(y + pp[u] * Cout + cg * V, o);
+            }
         }
         return;
     }
