@@ -368,3 +368,34 @@ def test_full_size_properties_c2(M):
         full = m(x)
         halves = torch.cat([m(x[:8]), m(x[8:])], 0)
     assert torch.equal(full, halves)
+
+
+def test_torch_compile_wrapper_is_transparent(M):
+    """The reference's TrainingWrapper calls torch.compile(model) (models/model_wrappers.py:118).  Our forwards are
+    torch.compiler.disable'd: the compiled wrapper must run the same HIP path (bit-identical results), expose the
+    `_orig_mod.` state_dict keys the reference's checkpoints carry, and train."""
+    m = M.un.UNet()
+    fill.fill_state_dict(m.state_dict())
+    m = m.cuda().train()
+    x = T("c1.x", (2, 3, 128, 128)).cuda()
+    t = torch.from_numpy(fill.randint("c1.t", (2, 128, 128), 3)).cuda()
+    crit = M.ls.HybridLoss()
+
+    def step(net):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda"):
+            out = net(x)
+            loss = crit(out, t)
+        loss.backward()
+        return out.detach().clone(), float(loss.detach()), m.out.weight.grad.clone(), m.enc1.block[0].conv[0].weight.grad.clone()
+
+    o0, l0, g0, h0 = step(m)
+    cm = torch.compile(m)
+    o1, l1, g1, h1 = step(cm)
+    assert torch.equal(o0, o1) and l0 == l1 and torch.equal(g0, g1) and torch.equal(h0, h1)
+    keys = list(cm.state_dict().keys())
+    assert len(keys) == 124 and all(k.startswith("_orig_mod.") for k in keys)
+    import hipseg.ckpt as ck
+    fresh = M.un.UNet()
+    ck.load_reference_checkpoint(fresh, {k: v.cpu() for k, v in cm.state_dict().items()})
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(fresh.state_dict().values(), m.state_dict().values()))
