@@ -102,46 +102,48 @@ struct PackDesc {
     long total0, total1;
 };
 
-template <typename T>
-__global__ void pack_batch_kernel(const PackDesc* __restrict__ descs, int G) {
+// thread = one G-element run (tap, k-group, n) of one operand: G gathered fp32 reads, ONE G*sizeof(T)-byte store
+// (16 B for bf16).  n is the fastest index, so a wave writes 1 KiB contiguous; all index math is 32-bit.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     const float* __restrict__ w = d.w;
-    T* __restrict__ wp = reinterpret_cast<T*>(d.wp);
-    T* __restrict__ wpt = reinterpret_cast<T*>(d.wpt);
-    const long total = d.total0 > d.total1 ? d.total0 : d.total1;
-    const int ks = d.ks, Cout = d.Cout, Cin = d.Cin;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        if (idx < d.total0) {
-            const int g = (int)(idx % G);
-            const int n = (int)((idx / G) % d.Np0);
-            const int kg = (int)((idx / ((long)G * d.Np0)) % (d.Kp0 / G));
-            const int tap = (int)(idx / ((long)d.Kp0 * d.Np0));
+    const int ks = d.ks, Cout = d.Cout, Cin = d.Cin, kk = ks * ks;
+    const int nv0 = (int)(d.total0 / G), nv1 = (int)(d.total1 / G);
+    const int stride = gridDim.x * blockDim.x;
+    typedef T vecT __attribute__((ext_vector_type(G)));
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nv0 + nv1; idx += stride) {
+        const bool second = idx >= nv0;
+        const int v = second ? idx - nv0 : idx;
+        const int Np = second ? d.Np1 : d.Np0, KG = (second ? d.Kp1 : d.Kp0) / G;
+        const int n = v % Np, kg = (v / Np) % KG, tap = v / (Np * KG);
+        float val[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
             const int k = kg * G + g;
-            float v = 0.f;
-            if (d.kind == 0) {  // K = Cin, N = Cout
-                const int ky = tap / ks, kx = tap % ks;
-                if (k < Cin && n < Cout) v = w[(((long)n * Cin + k) * ks + ky) * ks + kx];
-            } else if (k < Cin && n < 4 * Cout) {  // ConvT forward: 1 tap, K = Cin, N = 4*Cout, n = ab*Cout + co
-                const int ab = n / Cout, co = n % Cout;
-                v = w[((long)k * Cout + co) * 4 + ab];
+            float x = 0.f;
+            if (d.kind == 0) {
+                const int ky = tap / ks, kx = tap - ky * ks;
+                if (!second) {  // forward operand: K = Cin, N = Cout
+                    if (k < Cin && n < Cout) x = w[((long)n * Cin + k) * kk + ky * ks + kx];
+                } else {        // data-gradient operand: K = Cout, N = Cin, taps flipped
+                    if (k < Cout && n < Cin) x = w[((long)k * Cin + n) * kk + (ks - 1 - ky) * ks + (ks - 1 - kx)];
+                }
+            } else if (!second) {  // ConvT forward: 1 tap, K = Cin, N = 4*Cout, n = ab*Cout + co
+                if (k < Cin && n < 4 * Cout) {
+                    const int ab = n / Cout, co = n - ab * Cout;
+                    x = w[((long)k * Cout + co) * 4 + ab];
+                }
+            } else {               // ConvT data gradient: tap = ab, K = Cout, N = Cin
+                if (k < Cout && n < Cin) x = w[((long)n * Cout + k) * 4 + tap];
             }
-            wp[idx] = (T)v;
+            val[g] = x;
         }
-        if (idx < d.total1) {
-            const int g = (int)(idx % G);
-            const int n = (int)((idx / G) % d.Np1);
-            const int kg = (int)((idx / ((long)G * d.Np1)) % (d.Kp1 / G));
-            const int tap = (int)(idx / ((long)d.Kp1 * d.Np1));
-            const int k = kg * G + g;
-            float v = 0.f;
-            if (d.kind == 0) {  // K = Cout, N = Cin, taps flipped
-                const int ky = tap / ks, kx = tap % ks;
-                if (k < Cout && n < Cin) v = w[(((long)k * Cin + n) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
-            } else if (k < Cout && n < Cin) {  // ConvT data gradient: tap = ab, K = Cout, N = Cin
-                v = w[((long)n * Cout + k) * 4 + tap];
-            }
-            wpt[idx] = (T)v;
-        }
+        vecT o;
+#pragma unroll
+        for (int g = 0; g < G; ++g) o[g] = (T)val[g];
+        T* dst = reinterpret_cast<T*>(second ? d.wpt : d.wp) + (size_t)v * G;
+        *reinterpret_cast<vecT*>(dst) = o;
     }
 }
 
@@ -244,13 +246,16 @@ extern "C" int hipseg_pack_batch(const void* dev_descs, int n, int dtype, long m
     HS_REQUIRE(dev_descs && n > 0 && max_total > 0, "pack_batch: bad arguments");
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "pack_batch: bad dtype");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    long gx = (max_total + 255) / 256;
-    if (gx > 256) gx = 256;
+    // max_total bounds one operand; a descriptor's two operands are walked by one grid-stride loop
+    const int G = dtype == HIPSEG_BF16 ? 8 : 1;
+    long gx = (2 * max_total / G + 1023) / 1024;  // ~4 runs per thread for the largest weight
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n);
     if (dtype == HIPSEG_BF16)
-        hipLaunchKernelGGL(pack_batch_kernel<bf16>, grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs), 8);
+        hipLaunchKernelGGL((pack_batch_kernel<bf16, 8>), grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs));
     else
-        hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs), 1);
+        hipLaunchKernelGGL((pack_batch_kernel<float, 1>), grid, dim3(256), 0, s, reinterpret_cast<const PackDesc*>(dev_descs));
     HS_LAUNCH_CHECK("pack_batch");
     return HIPSEG_OK;
 }
