@@ -453,7 +453,8 @@ struct DmaBufs {
 // 0.75 LDS fragment reads per MFMA instead of 1.0, and the weight chunk is amortised over twice the pixels --
 // the main loop is LDS-bandwidth bound: fragment reads + DMA writes share the LDS port with nothing to spare).
 template <int MODE, int BN, int THT = 16>
-__global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm_dma_kernel(ConvArgs p) {
+__global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>::value == 8 ? 1 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int NW = DmaWaves<BN, THT>::value, NBUF = DmaBufs<BN, THT>::value, DIST = NBUF - 1;
     typedef bf16 T;
     constexpr int KC = 16, KG = 2;
@@ -503,8 +504,28 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.wp);
     const T* zero = reinterpret_cast<const T*>(&g_zero16);
 
-    // per-lane source pixel of each of this wave's A pieces (piece = 64 consecutive halo pixels of one octet)
-    long apix[NAW];
+    // ---- LDS-DMA through BUFFER addressing (buffer_load_dwordx4 ... lds): a piece's per-lane byte offset never changes
+    // from chunk to chunk (it is computed once, below), the chunk only moves a scalar offset, and a lane that must read
+    // zeros (image border, padding pixel) carries an out-of-range offset -- the hardware bounds check writes 0 to LDS.
+    // A piece therefore costs a handful of SALU instructions and NO vector ALU work: the tap loop was issue-bound
+    // (per tap ~40 address / branch instructions against 4 MFMAs per wave), not MFMA- or LDS-bound.
+    // Offsets: valid < 2^30 (launch condition: tensors <= 1 GiB), lane out of range = 2^31, chunk out of range = +2^30.
+    constexpr unsigned OOB_LANE = 0x80000000u, OOB_CHUNK = 0x40000000u;
+    const unsigned bytes0 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C0 * sizeof(T));
+    const unsigned bytes1 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C1 * sizeof(T));
+    const __amdgpu_buffer_rsrc_t r_in0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in0), 0, (int)bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_in1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in1 ? p.in1 : p.in0), 0, (int)bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.wp), 0, (int)((size_t)NT * p.Kp * p.Np * sizeof(T)), 0x00020000);
+    (void)in0;
+    (void)in1;
+    (void)wp;
+    (void)zero;
+
+    // per-lane byte offset of the lane's source pixel for each of this wave's A pieces (piece = 64 consecutive halo
+    // pixels of one k-octet), against either source tensor
+    unsigned avo0[NAW], avo1[NAW];
     int aoct[NAW];
 #pragma unroll
     for (int j = 0; j < NAW; ++j) {
@@ -513,37 +534,61 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
         const int pix = (s % (NPIXP / 64)) * 64 + lane;
         const int iy = oy + pix / HW, ix = ox + pix % HW;
         const bool ok = s < NA && pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        apix[j] = ok ? ((long)img * p.Hi + iy) * p.Wi + ix : -1;
+        const long apix = ((long)img * p.Hi + iy) * p.Wi + ix;
+        avo0[j] = ok ? (unsigned)(apix * p.C0 * (long)sizeof(T)) : OOB_LANE;
+        avo1[j] = ok ? (unsigned)(apix * p.C1 * (long)sizeof(T)) : OOB_LANE;
     }
     const int kgp = p.Kp / 8;
+    // per-lane byte offset into the packed weights for each B piece (everything but the chunk's k-octet term)
+    unsigned bvo[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int s = j * NW + wave;
+        const int bb = s * 1024 + lane * 16;
+        const int run = bb / RUNB, off = bb % RUNB;
+        const int tap = run / KG, kgl = run % KG;
+        bvo[j] = s < NB ? (unsigned)((((size_t)tap * kgp + kgl) * p.Np + n0) * 16 + off) : OOB_LANE;
+    }
 
-    // one 1-KiB DMA piece of chunk c0 into ring buffer `buf`; idx < NAW: this wave's idx-th A piece,
-    // otherwise its (idx - NAW)-th B piece.  Issued one at a time BETWEEN MFMA groups (an LDS-DMA holds the
-    // wave's issue port for ~100 cycles; issued in a burst after the barrier they idle the matrix pipe).
+    // The two operands take DIFFERENT roads into LDS.  LDS-DMA lands only ~12 B/clk per CU; with both operands on
+    // it a 16-channel chunk (12-20 KiB of activations + 36 KiB of weights for a 128-wide tile) takes ~4000 cycles
+    // against 2304 cycles of MFMA work (measured: either operand alone costs +3-4 us on a 55-us kernel, both +27 us).
+    // So only the activations (per-lane halo gather, zero fill) use LDS-DMA; the weight chunk -- contiguous, L2
+    // resident, shared by every workgroup -- is read into VGPRs (buffer_load_dwordx4, one chunk ahead, at the top
+    // of the chunk) and written to its ring slot with ds_write_b128 after the chunk's MFMAs.
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i bst[NBW];
+    auto loadB = [&](int c0) {
+        const unsigned so = !(p.debug & 2) ? (unsigned)(c0 / 8) * (unsigned)p.Np * 16u : OOB_CHUNK;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bst[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_w, bvo[j], so, 0));
+    };
+    auto writeB = [&](int buf) {
+        unsigned char* base = smem + buf * BUF + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int s = j * NW + wave;
+            if ((j + 1) * NW <= NB || s < NB) *reinterpret_cast<v4i*>(base + s * 1024 + lane * 16) = bst[j];
+        }
+    };
+    // one 1-KiB DMA piece (64 halo pixels of one k-octet) of chunk c0 into ring buffer `buf`, issued one at a time
+    // BETWEEN MFMA groups; every wave issues NAW per chunk (pad pieces go to the sink) so waits can be counted
     auto issue_piece = [&](int buf, int c0, int idx) {
         unsigned char* base = smem + buf * BUF;
         unsigned char* dummy = smem + NBUF * BUF;  // 1-KiB sink for the pad pieces of waves with fewer real ones
-        if (idx < NAW) {
-            const int s = idx * NW + wave;
-            const bool real = s < NA && !(p.debug & 1);
-            const int c = c0 + aoct[idx] * 8;
-            const T* src = zero;
-            if (real && apix[idx] >= 0 && c < p.K)
-                src = (c < p.C0) ? in0 + apix[idx] * p.C0 + c : in1 + apix[idx] * p.C1 + (c - p.C0);
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + s * 1024 : dummy), 16, 0, 0);
+        const int s = idx * NW + wave;
+        const bool real = s < NA;
+        const int c = c0 + aoct[idx] * 8;  // wave-uniform: first channel of the piece's octet
+        lds_void* dst = (lds_void*)(real ? base + s * 1024 : dummy);
+        if (c < p.C0 || p.C1 == 0) {
+            const unsigned so = (c < p.K && !(p.debug & 1)) ? (unsigned)c * (unsigned)sizeof(T) : OOB_CHUNK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in0, dst, 16, avo0[idx], so, 0, 0);
         } else {
-            const int s = (idx - NAW) * NW + wave;
-            const bool real = s < NB && !(p.debug & 2);
-            const int b = s * 1024 + lane * 16;
-            const int run = b / RUNB, off = b % RUNB;
-            const int tap = run / KG, kgl = run % KG;
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(zero);
-            if (real) src = wp + (((size_t)tap * kgp + c0 / 8 + kgl) * p.Np + n0) * 16 + off;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + A_BYTES + s * 1024 : dummy), 16, 0,
-                                             0);
+            const unsigned so = (c < p.K && !(p.debug & 1)) ? (unsigned)(c - p.C0) * (unsigned)sizeof(T) : OOB_CHUNK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in1, dst, 16, avo1[idx], so, 0, 0);
         }
     };
-    constexpr int NPCW = NAW + NBW;                 // pieces per wave per chunk
+    constexpr int NPCW = NAW;                       // LDS-DMA pieces per wave per chunk (activations only)
     // pieces issued per tap: at least IGEMM_PPT, so that a chunk's pieces all go out in its FIRST taps and have the
     // rest of the chunk's MFMA time to land (spread evenly, the last piece is issued just before the barrier that
     // waits for it)
@@ -570,13 +615,15 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
     if (p.stagger && ((blockIdx.x / p.ncu) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    // prologue: the first DIST chunks go out at once
+    // prologue: the activation pieces of the first DIST chunks go out at once; weight chunk 0 through registers
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
         if (d < nchunks) {
 #pragma unroll
             for (int q = 0; q < NPCW; ++q) issue_piece(d, d * KC, q);
         }
+    loadB(0);
+    writeB(0);
     int cur = 0;  // ring slot of chunk kc
     for (int kc = 0; kc < nchunks; ++kc) {
         // every wave issues exactly NPCW pieces per chunk, so "chunk kc has landed" is a COUNTED wait that
@@ -585,9 +632,12 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NPCW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's weight-chunk ds_writes
         __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone left the slot chunk kc+DIST will fill
         __builtin_amdgcn_sched_barrier(0);
         const bool more = kc + DIST < nchunks;
+        const bool moreB = kc + 1 < nchunks;
+        if (moreB) loadB((kc + 1) * KC);  // next chunk's weights -> VGPRs, written to LDS after this chunk's MFMAs
         const int nbuf = (cur + DIST) % NBUF, nc0 = (kc + DIST) * KC;
         const unsigned char* sA = smem + cur * BUF;
         const unsigned char* sB = sA + A_BYTES;
@@ -609,6 +659,7 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
 #pragma unroll
                 for (int q = 0; q < NPCW; ++q) issue_piece(nbuf, nc0, q);
             }
+            if (moreB) writeB(cur);
             continue;
         }
         fetch(0, 0);
@@ -636,9 +687,13 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), 2) void conv_igemm
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (moreB) writeB(cur);  // `cur` already names the next chunk's slot (free since the barrier above)
     }
 
     if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+#else
+    (void)p;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1386,7 +1441,11 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
             return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
         }
-        if (a.vec_ok && !no_dma) {
+        // the ring kernel addresses its operands through buffer descriptors with 2^30 / 2^31 out-of-range markers
+        const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
+        const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
+        const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
+        if (a.vec_ok && !no_dma && buf_ok) {
             // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)
             static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
             const long tall_wgs = (long)a.B * a.tiles_x * cdiv(H, 32) * a.ntn;
