@@ -697,6 +697,203 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 ring kernel with ACTIVATION SUPER-CHUNKS (128-wide tile, >= 128 input channels).  The plain ring kernel gathers
+// 16 B (one k-octet) per halo pixel per DMA lane and comes back for the neighbouring octets of the same cache line
+// one, two and three 16-channel chunks later -- long after the line left the 32-KiB L1 -- so every activation line is
+// requested from the L2 two to eight times, 64 requests per DMA instruction.  With the weight chunk's traffic on top
+// the memory system, not the MFMA pipe, sets the chunk time (measured on 256->256 @64^2: either operand alone costs
+// +3-4 us on a 55-us kernel, both together +27 us).  Here the halo tile is staged SO octets (SO * 8 channels = 64 or
+// 128 B per pixel) at a time into its own 2-slot LDS ring: the SO DMA instructions that touch a line are issued back
+// to back by the waves of the workgroup, one L2 request serves them all, and the K loop walks SO / 2 chunks inside a
+// resident super-chunk.  Weights: one 16-channel chunk ahead through registers (see conv_igemm_dma_kernel).
+template <int THT, int SO>
+struct A64Geo {
+    static constexpr int BN = 128, NW = 8, KC = 16, KG = 2, NT = 9, SCH = SO / 2;  // chunks per super-chunk
+    static constexpr int HW = TW + 2, HH = THT + 2, NPIX = HH * HW;
+    static constexpr int NGRP = (NPIX + 63) / 64, NPIXA = NGRP * 64;       // 64-pixel groups of the halo tile
+    static constexpr int A_BYTES = SO * NPIXA * 16, NAP = SO * NGRP;       // DMA pieces per super-chunk
+    static constexpr int NAW = (NAP + NW - 1) / NW;                        // per wave
+    static constexpr int B_BYTES = NT * KG * BN * 16, NB = B_BYTES / 1024, NBW = (NB + NW - 1) / NW;
+    static constexpr size_t RING = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES + 1024;  // + sink
+    static constexpr size_t SCRATCH = (size_t)NW * 32 * (BN / 2) * sizeof(float);      // epilogue transposes
+    static constexpr size_t LDS = RING > SCRATCH ? RING : SCRATCH;
+    static_assert(A_BYTES % 1024 == 0 && LDS <= 160 * 1024, "geometry");
+};
+
+template <int THT, int SO>
+__global__ __launch_bounds__(512, 1) void conv3_ring64_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+    typedef A64Geo<THT, SO> G;
+    typedef bf16 T;
+    constexpr int MODE = HIPSEG_CONV3, BN = G::BN, NW = G::NW, KC = G::KC, KG = G::KG, NT = G::NT, SCH = G::SCH;
+    constexpr int HW = G::HW, NPIX = G::NPIX, NPIXA = G::NPIXA, A_BYTES = G::A_BYTES, NAP = G::NAP, NAW = G::NAW;
+    constexpr int B_BYTES = G::B_BYTES, NB = G::NB, NBW = G::NBW, RUNB = BN * 16;
+    constexpr int WN = WG<BN, NW, THT>::WN, MT = WG<BN, NW, THT>::MT, NTL = WG<BN, NW, THT>::NTL;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB_LANE = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ringA = smem;
+    unsigned char* const ringB = smem + 2 * A_BYTES;
+    unsigned char* const sink = smem + 2 * A_BYTES + 2 * B_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_block(blockIdx.x, p.xcd);
+    const int ntile = bid % p.ntn, mtile = bid / p.ntn;
+    const int tx = mtile % p.tiles_x;
+    const int ty = (mtile / p.tiles_x) % p.tiles_y;
+    const int img = mtile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * THT, x0 = tx * TW, n0 = ntile * BN;
+
+    const unsigned bytes0 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C0 * sizeof(T));
+    const unsigned bytes1 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C1 * sizeof(T));
+    const __amdgpu_buffer_rsrc_t r_in0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in0), 0, (int)bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_in1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in1 ? p.in1 : p.in0), 0, (int)bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.wp), 0, (int)((size_t)NT * p.Kp * p.Np * sizeof(T)), 0x00020000);
+
+    // A piece q = (pixel group q / SO, octet q % SO): 64 pixels of one k-octet, 1 KiB contiguous in the [octet][pixel]
+    // image.  The SO pieces of a pixel group -- the SO 16-byte parts of the same cache lines -- belong to SO different
+    // waves and are issued at the same step of the walk (L1 serves all but the first).  Per-lane byte offsets against
+    // either source tensor; border / padding pixels are out of range (zero fill).
+    unsigned avo0[NAW], avo1[NAW];
+#pragma unroll
+    for (int j = 0; j < NAW; ++j) {
+        const int q = j * NW + wave;
+        const int oct = q % SO, pix = (q / SO) * 64 + lane;
+        const int iy = y0 - 1 + pix / HW, ix = x0 - 1 + pix % HW;
+        const bool ok = q < NAP && pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const long apix = ((long)img * p.Hi + iy) * p.Wi + ix;
+        avo0[j] = ok ? (unsigned)(apix * p.C0 * (long)sizeof(T) + oct * 16) : OOB_LANE;
+        avo1[j] = ok ? (unsigned)(apix * p.C1 * (long)sizeof(T) + oct * 16) : OOB_LANE;
+    }
+    const int kgp = p.Kp / 8;
+    unsigned bvo[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int s = j * NW + wave;
+        const int bb = s * 1024 + lane * 16;
+        const int run = bb / RUNB, off = bb % RUNB;
+        const int tap = run / KG, kgl = run % KG;
+        bvo[j] = s < NB ? (unsigned)((((size_t)tap * kgp + kgl) * p.Np + n0) * 16 + off) : OOB_LANE;
+    }
+    v4i bst[NBW];
+    auto loadB = [&](int c0) {
+        const unsigned so = (unsigned)(c0 / 8) * (unsigned)p.Np * 16u;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bst[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_w, bvo[j], so, 0));
+    };
+    auto writeB = [&](int slot) {
+        unsigned char* base = ringB + slot * B_BYTES;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int s = j * NW + wave;
+            if ((j + 1) * NW <= NB || s < NB) *reinterpret_cast<v4i*>(base + s * 1024 + lane * 16) = bst[j];
+        }
+    };
+    // idx-th A piece of this wave for the super-chunk starting at channel sc0 (launch condition: a super-chunk lies
+    // inside ONE source tensor and inside K)
+    auto pieceA = [&](int slotA, int sc0, int idx) {
+        const int q = idx * NW + wave;
+        lds_void* dst = (lds_void*)(((idx + 1) * NW <= NAP || q < NAP)
+                                        ? ringA + slotA * A_BYTES + ((q % SO) * NPIXA + (q / SO) * 64) * 16
+                                        : sink);
+        if (sc0 < p.C0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in0, dst, 16, avo0[idx], (unsigned)sc0 * (unsigned)sizeof(T), 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in1, dst, 16, avo1[idx], (unsigned)(sc0 - p.C0) * (unsigned)sizeof(T),
+                                                     0, 0);
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int hbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) hbase[i] = (2 * (wm * MT + i) + (r >> 4)) * HW + sub_px<MODE>(r);
+    int ncol[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
+
+    const int nchunks = p.Kp / KC, nsuper = nchunks / SCH;
+    // prologue: super-chunk 0 and weight chunk 0
+#pragma unroll
+    for (int q = 0; q < NAW; ++q) pieceA(0, 0, q);
+    loadB(0);
+    writeB(0);
+    constexpr int SLOTS = SCH * NT;                  // (chunk, tap) steps inside a super-chunk
+    constexpr int PSTEP = SLOTS / NAW > 0 ? SLOTS / NAW : 1;  // a DMA piece every PSTEP steps
+    static_assert((NAW - 1) * PSTEP < SLOTS, "all pieces of the next super-chunk are issued inside the current one");
+    for (int su = 0; su < nsuper; ++su) {
+        const bool moreA = su + 1 < nsuper;
+        const unsigned char* sA = ringA + (su & 1) * A_BYTES;
+#pragma unroll
+        for (int kl = 0; kl < SCH; ++kl) {
+            const int kc = su * SCH + kl;
+            // first chunk of a super-chunk: its pieces (issued during the previous super-chunk) must have landed
+            if (kl == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's weight-chunk ds_writes
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool moreB = kc + 1 < nchunks;
+            if (moreB) loadB((kc + 1) * KC);
+            const unsigned char* sB = ringB + (kc & 1) * B_BYTES;
+            bf16x8 bf[2][NTL], af[2][MT];
+            auto fetch = [&](int slot, int tap) {
+                const int toff = tap_off<MODE>(tap);
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    bf[slot][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(tap * KG + h) * BN + ncol[j]) * 16);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[slot][i] =
+                        *reinterpret_cast<const bf16x8*>(sA + ((size_t)(kl * 2 + h) * NPIXA + hbase[i] + toff) * 16);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) {
+                constexpr int HALF = (MT + 1) / 2;
+#pragma unroll
+                for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap + 1 < NT) fetch((tap + 1) & 1, tap + 1);
+                {
+                    const int step = kl * NT + tap;
+                    if (moreA && step % PSTEP == 0 && step / PSTEP < NAW)
+                        pieceA((su + 1) & 1, (su + 1) * SCH * KC, step / PSTEP);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = HALF; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][i], bf[tap & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (moreB) writeB((kc + 1) & 1);
+        }
+    }
+    conv_epilogue<bf16, MODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+#else
+    (void)p;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Persistent form of the 256x128 bf16 kernel (one 512-thread workgroup per CU walks a strided list of
 // output tiles).  The (tile, K-chunk) sequence is ONE software pipeline: the LDS-DMA of the next tile's
 // first chunk is in flight while the last chunk of the current tile computes (no per-tile prologue bubble),
@@ -1292,6 +1489,25 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     return HIPSEG_OK;
 }
 
+template <int THT, int SO>
+int launch_ring64(const ConvArgs& a0, hipStream_t s) {
+    typedef A64Geo<THT, SO> G;
+    ConvArgs a = a0;
+    a.tiles_y = cdiv(a.H, THT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring64_kernel<THT, SO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+        attr_set = true;
+    }
+    const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
+    a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
+    hipLaunchKernelGGL((conv3_ring64_kernel<THT, SO>), dim3((unsigned)grid), dim3(512), G::LDS, s, a);
+    HS_LAUNCH_CHECK("conv3_ring64");
+    return HIPSEG_OK;
+}
+
 template <int MODE>
 int launch_dma_bn(const ConvArgs& a, int bn, hipStream_t s) {
     if (bn == 128) return launch_dma<MODE, 128>(a, s);
@@ -1449,6 +1665,13 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)
             static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
             const long tall_wgs = (long)a.B * a.tiles_x * cdiv(H, 32) * a.ntn;
+            // 128-wide tiles whose K splits into whole activation super-chunks inside one source tensor
+            static const bool no_r64 = getenv("HIPSEG_NO_RING64") != nullptr;
+            const bool tall = mode == HIPSEG_CONV3 && !no_tall && H >= 32 && bn >= 64 && tall_wgs >= (bn == 128 ? 256 : 512);
+            if (mode == HIPSEG_CONV3 && bn == 128 && !no_r64 && !dbg && a.K == a.Kp) {
+                if (a.Kp % 32 == 0 && (C1 == 0 || C0 % 32 == 0))
+                    return tall ? launch_ring64<32, 4>(a, s) : launch_ring64<16, 4>(a, s);
+            }
             if (mode == HIPSEG_CONV3 && !no_tall && H >= 32 && bn >= 64 && tall_wgs >= (bn == 128 ? 256 : 512)) {
                 if (bn == 128) return launch_dma<HIPSEG_CONV3, 128, 32>(a, s);
                 return launch_dma<HIPSEG_CONV3, 64, 32>(a, s);  // (32-wide tiles measured slower tall)
