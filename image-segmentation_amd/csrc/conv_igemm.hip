@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
 
     // one 1-KiB piece (octet, 64-pixel group) of the tile under the staging cursor
     auto piece = [&](int j, unsigned char* base, int img, int y0, int x0, bool live) {
-        const int oct = wave * OPW + j / NG, g = j % NG;
+        const int oct = wave * OPW + j % OPW, g = j / OPW;  // the octets of one pixel group at adjacent steps (L1 reuse)
         const int c0 = oct * 8;  // wave-uniform
         const T* src0;
         int cs;
