@@ -114,12 +114,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # the data-parallel code path (HipDDP, split hipGraphs around the RCCL all-reduce); HIPSEG_BENCH_FORCE_DDP=1 takes
+    # it with a 1-rank process group, to rehearse it on a single-GPU box
+    ddp = world > 1 or bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world)
 
     import hipseg
@@ -138,7 +142,7 @@ def main():
     else:
         model = getattr(un, args.model)().to(dev).train()
     use_graph = args.loop == "graph"
-    net = HipDDP(model, overlap=not use_graph) if world > 1 else model
+    net = HipDDP(model, overlap=not use_graph) if ddp else model
     crit = HybridLoss()
     opt = torch.optim.Adam([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=1e-4, fused=True,
                            capturable=use_graph)
@@ -154,7 +158,7 @@ def main():
             out = (model if use_graph else net)(x)  # graph mode: buffer broadcast is issued outside the graph
             loss = crit(out, t)
         scaler.scale(loss).backward()
-        if world > 1 and use_graph:
+        if ddp and use_graph:
             net.pack_gradients()
         return loss
 
@@ -164,14 +168,14 @@ def main():
 
     def step():
         loss = fwd_bwd()
-        if world > 1 and use_graph:
+        if ddp and use_graph:
             net.allreduce_packed()
         opt_step()
         return loss
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,12 +189,12 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                if world > 1:
+                if ddp:
                     net.broadcast_buffers_now()
                 loss = step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if world == 1:
+        if not ddp:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = step()
@@ -223,7 +227,7 @@ def main():
         loss = run()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -278,7 +282,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
-    if world > 1:
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
