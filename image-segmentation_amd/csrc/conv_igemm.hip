@@ -14,6 +14,13 @@
 //
 // The epilogue adds the bias, stores NHWC (optionally split over two destination tensors, or
 // pixel-shuffled for ConvTranspose2d) and reduces the per-tile BatchNorm partial sums.
+//
+// Kernels in this file (bf16 unless noted; dispatch in hipseg_conv_igemm):
+//   conv3_wstat_kernel     3x3, <= 64 channels on both sides, >= 1024 tiles: weights in registers, persistent
+//   conv3_ring64_kernel    3x3, 128-wide tiles, K % 32 == 0: activation super-chunks + register-staged weights
+//   conv_igemm_dma_kernel  every other vector-aligned shape / mode (ring of 16-channel chunks)
+//   conv_igemm_pers_kernel opt-in persistent form of the ring kernel (HIPSEG_PERSISTENT=1; measured slower)
+//   conv_igemm_kernel      fp32 and channel counts that are not multiples of 8 (register-staged, single buffer)
 #include <stdlib.h>
 
 #include "common.h"
