@@ -68,6 +68,11 @@ CONV_CASES = [
     (1, 128, 0, 256, 8, 8),
     (1, 24, 0, 40, 16, 16),
     (1, 5, 0, 7, 10, 18),
+    # 128-wide tiles with K % 32 == 0: the super-chunk ring kernel (dual source / dual destination, ragged borders,
+    # a tall-tile geometry with >= 256 workgroups)
+    (1, 64, 64, 128, 24, 40),
+    (1, 96, 32, 160, 18, 30),
+    (4, 128, 0, 128, 128, 128),
     # >= 1024 tiles of 8x16 pixels with <= 64 channels: the weights-stationary persistent kernel (all four
     # K/N shapes between fwd and dgrad, dual source / dual destination, ragged image borders)
     (2, 64, 0, 64, 256, 256),
