@@ -380,27 +380,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
             for (int e = 0; e < V; ++e) s[e] += v[e];
         }
     }
-    const int R = 2048 / C;
-    float t[V];
+    // PL * C <= 2048 floats: one LDS round, then column-parallel sums in row order (see bn_bwd_reduce_kernel)
+    if (pl < PL) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) t[e] = 0.f;
-    for (int base = 0; base < PL; base += R) {
-        __syncthreads();
-        if (pl >= base && pl < base + R && pl < PL) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) red[(pl - base) * C + cg * V + e] = s[e];
-        }
-        __syncthreads();
-        if (pl == 0) {
-            const int lim = (PL - base) < R ? (PL - base) : R;
-            for (int j = 0; j < lim; ++j)
-#pragma unroll
-                for (int e = 0; e < V; ++e) t[e] += red[j * C + cg * V + e];
-        }
+        for (int e = 0; e < V; ++e) red[pl * C + cg * V + e] = s[e];
     }
-    if (pl == 0) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) partial[(size_t)blockIdx.x * C + cg * V + e] = t[e];
+    __syncthreads();
+    for (int col = tid; col < C; col += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < PL; ++j) acc += red[j * C + col];
+        partial[(size_t)blockIdx.x * C + col] = acc;
     }
 }
 

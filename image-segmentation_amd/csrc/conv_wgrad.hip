@@ -567,7 +567,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
 // LDS so the native (Cout=v, Cin=u, ky, kx) write is 576-byte runs (144 consecutive floats per v).
 __global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                              int S, int sstep, int CU, int CV, int CUp, int CVp) {
-    __shared__ float tile[16 * 16 * 9];
+    __shared__ float tile[16 * 145];  // 144 floats per v row + 1 pad: the transposing writes spread over 16 banks
     const int tid = threadIdx.x;
     const int u = tid >> 4, v = tid & 15;
     const int u0 = blockIdx.y * 16, v0 = blockIdx.x * 16;
@@ -581,14 +581,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restr
         for (int t = 0; t < 9; ++t) acc[t] += src[s * sstride + t * tstride];
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tile[(v * 16 + u) * 9 + t] = acc[t];
+    for (int t = 0; t < 9; ++t) tile[v * 145 + u * 9 + t] = acc[t];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int idx = k * 256 + tid;
         const int vv = idx / 144, rem = idx % 144;
         const int uu = rem / 9, t = rem % 9;
-        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t] = tile[idx];
+        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t] = tile[vv * 145 + rem];
     }
 }
 
