@@ -6,6 +6,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no WORLD_SIZE in the environment, this process only LAUNCHES: before any GPU call it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` as a child (fresh rank processes), relays rank 0's
+JSON line and exits with the child's code.  Fewer than N visible devices, or WORLD_SIZE != N, is an error.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel (most device time) of the step -- achieved algorithmic
                  TFLOP/s from HIP-event timing of every launch of that kernel, vs the dense bf16
@@ -16,8 +20,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   kernels      : per-kernel breakdown from the same event timing (informational).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,8 +46,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet"])
-    ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "graph"), choices=["eager", "graph"],
-                    help="eager: Python launches every kernel each step; graph: the whole step is one hipGraph replay")
+    ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "graph"),
+                    choices=["eager", "graph", "splitgraph"],
+                    help="graph: the whole step is ONE hipGraph replay; for N > 1 the bucketed RCCL all-reduces are "
+                         "captured inside it as side-stream branches overlapped with backward.  eager: Python "
+                         "launches every kernel each step (all-reduce overlapped from autograd hooks).  splitgraph "
+                         "(N > 1 only): hipGraph(fwd+bwd+pack) -> eager all-reduce (NOT overlapped) -> hipGraph(optimizer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -85,46 +96,89 @@ def _config_index(args, world):
 
 
 # HBM traffic of the roofline kernel comes from committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share
-# a pass; PMC collection cannot run inside the timed bench): profiles/r01_pmc_traffic.json, made by
+# a pass; PMC collection cannot run inside the timed bench): profiles/r02_pmc_traffic.json, made by
 # scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --loop eager`.
-_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": ("wgrad_dma_kernel<9,", "wgrad_reduce3_kernel", "colreduce_inplace_kernel"),
-                "conv_igemm<bf16,CONV3,BN128>": ("conv_igemm_dma_kernel<0, 128,",)}
+# The file records the sha256 of the kernel sources it was measured on; a mismatch with the sources of THIS run means
+# the numbers are stale and `traffic` is reported as null.
+_PMC_FILE = "r02_pmc_traffic.json"
+_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": ("wgrad_dma_kernel<9,", "wgrad_reduce", "colreduce_inplace_kernel"),
+                "conv_igemm<bf16,CONV3,BN128>": ("conv_igemm_dma_kernel<0, 128,", "conv3_ring64_kernel")}
+_PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "bn.hip", "common.h")
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in _PMC_SOURCES:
+        h.update(open(os.path.join(ROOT, "image-segmentation_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _pmc_traffic(key, args):
     """(average HBM bytes per launch of the roofline kernel, provenance) or (None, reason)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", _PMC_FILE)
     if (args.model, args.size, args.batch) != ("UNet", 256, 16) or key not in _PMC_KERNELS or not os.path.exists(path):
         return None, "no PMC pass for this kernel/config"
-    ks = json.load(open(path))["kernels"]
+    doc = json.load(open(path))
+    if doc.get("kernel_source_sha16") != kernel_source_hash():
+        return None, f"profiles/{_PMC_FILE} was measured on other kernel sources (stale): re-run scripts/pmc.sh"
+    ks = doc["kernels"]
     main_pat = _PMC_KERNELS[key][0]
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(p in k for p in _PMC_KERNELS[key]))
     n = sum(v["launches"] for k, v in ks.items() if main_pat in k)
-    return (round(tot / n), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)") \
+    return (round(tot / n), f"profiles/{_PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)") \
         if n else (None, "kernel not in the PMC pass")
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a torchrun environment: start N fresh rank processes.  Nothing in this process has
+    touched the GPU (torch.cuda.device_count() does not initialise HIP), and the ranks are CHILDREN, not an exec."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {ndev} GPU(s) are visible", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0:
+        if args.gpus > 1:
+            launch_ranks(args)  # never returns
+        world = 1
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # the data-parallel code path (HipDDP, split hipGraphs around the RCCL all-reduce); HIPSEG_BENCH_FORCE_DDP=1 takes
-    # it with a 1-rank process group, to rehearse it on a single-GPU box
-    ddp = world > 1 or bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP"))
+    # the data-parallel code path (HipDDP); HIPSEG_BENCH_FORCE_DDP=1 takes it with a 1-rank RCCL group and every
+    # collective still issued, to rehearse hooks / buckets / side stream / in-graph capture on a single-GPU box
+    force = bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP"))
+    ddp = world > 1 or force
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        print(f"bench.py: rank {rank} needs device {local}, {torch.cuda.device_count()} visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ctl = None
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world)
+        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
+        ctl = dist.new_group(backend="gloo")  # host-side agreement between ranks (never on the data path)
 
     import hipseg
     from hipseg import ops
@@ -141,8 +195,14 @@ def main():
         model = ClipUnet().to(dev).train()
     else:
         model = getattr(un, args.model)().to(dev).train()
-    use_graph = args.loop == "graph"
-    net = HipDDP(model, overlap=not use_graph) if ddp else model
+    loop = args.loop
+    if loop == "splitgraph" and not ddp:
+        loop = "graph"
+    use_graph = loop in ("graph", "splitgraph")
+    split = loop == "splitgraph"
+    # graph / eager: gradients are reduced bucket by bucket from autograd hooks on a side stream, overlapped with
+    # backward (north star); splitgraph: explicit pack + all-reduce between two graphs
+    net = HipDDP(model, overlap=not split, force_collectives=force) if ddp else model
     crit = HybridLoss()
     opt = torch.optim.Adam([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=1e-4, fused=True,
                            capturable=use_graph)
@@ -151,14 +211,15 @@ def main():
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
     t = torch.randint(0, 3, (args.batch, args.size, args.size), generator=g).to(dev)
 
-    # loop body of the reference's TrainingWrapper.train (models/model_wrappers.py:167-177), in two halves
+    # loop body of the reference's TrainingWrapper.train / DistributedTrainingWrapper.train
+    # (models/model_wrappers.py:167-177, 968-980), in two halves
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda"):
-            out = (model if use_graph else net)(x)  # graph mode: buffer broadcast is issued outside the graph
+            out = (model if split else net)(x)  # splitgraph: the buffer broadcast is issued outside the graph
             loss = crit(out, t)
-        scaler.scale(loss).backward()
-        if ddp and use_graph:
+        scaler.scale(loss).backward()  # HipDDP hooks: per-bucket all-reduce on the comm stream, joined at the end
+        if split:
             net.pack_gradients()
         return loss
 
@@ -168,7 +229,7 @@ def main():
 
     def step():
         loss = fwd_bwd()
-        if ddp and use_graph:
+        if split:
             net.allreduce_packed()
         opt_step()
         return loss
@@ -179,35 +240,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = None
-    if use_graph:
-        # eager warm-up on a side stream (allocator, lazy kernel attributes, RCCL communicators), then capture:
-        # N = 1: one hipGraph for the whole step.  N > 1: graph A = zero_grad + fwd + loss + scaled bwd + gradient
-        # pack, eager RCCL all-reduce of the flat buckets (and the DDP buffer broadcast), graph B = GradScaler +
-        # Adam reading the reduced bucket views.
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                if ddp:
-                    net.broadcast_buffers_now()
-                loss = step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if not ddp:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step()
+    def all_agree(ok):
+        if ctl is None:
+            return ok
+        f = torch.tensor([1 if ok else 0])
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=ctl)
+        return bool(f.item())
 
-            def run():
-                graph.replay()
-                return static_loss
+    # every step -- warm-up, capture, replay, eager -- runs on ONE non-default stream, so autograd's AccumulateGrad
+    # nodes, the capture and HipDDP's events all see the same stream
+    main_stream = torch.cuda.Stream()
+    main_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main_stream)
+    loss = None
+    loop_used = loop
+    if use_graph:
+        for _ in range(3):  # eager warm-up: allocator, lazy kernel attributes, RCCL communicators
+            if split:
+                net.broadcast_buffers_now()
+            loss = step()
+        torch.cuda.synchronize()
+        run = None
+        if not split:
+            # ONE hipGraph for the whole step.  N > 1: the hooks fire during capture, so each bucket's all-reduce is
+            # captured on the comm stream as a forked branch that runs under the remaining backward kernels.
+            err = None
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=main_stream):
+                    static_loss = step()
+            except Exception as e:  # noqa: BLE001
+                if not ddp:
+                    raise
+                err = e
+            if all_agree(err is None):
+                def run():
+                    graph.replay()
+                    return static_loss
+            else:
+                print(f"[rank {rank}] hipGraph capture with in-graph RCCL failed ({err!r}); falling back to the eager "
+                      "overlapped loop", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                loop_used = "eager"
+                run = step
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, stream=main_stream):
                 static_loss = fwd_bwd()
             net.use_bucket_grads()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream):
                 opt_step()
 
             def run():
@@ -222,9 +303,12 @@ def main():
     for _ in range(args.warmup):
         loss = run()
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = run()
+        evs[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if ddp:
@@ -234,6 +318,12 @@ def main():
     final_loss = float(loss.detach())
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
+    ev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    loop_desc = {"graph": "hipgraph (one graph per step" + ("; bucketed RCCL all-reduces captured on a side stream, "
+                                                             "overlapped with backward)" if ddp else ")"),
+                 "eager": "eager" + (" (bucketed RCCL all-reduce on a side stream from autograd hooks, overlapped "
+                                     "with backward)" if ddp else ""),
+                 "splitgraph": "hipgraph(fwd+bwd+pack) + eager RCCL all-reduce (not overlapped) + hipgraph(optimizer)"}
 
     out = {
         "metric": "images/sec (whole node) U-Net 3x256x256 train step" if (args.model, args.size) == ("UNet", 256)
@@ -245,21 +335,29 @@ def main():
                                f"{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch {args.batch}/GPU, "
                                f"BASELINE.json configs[{_config_index(args, world)}]",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}",
-                   "loop": ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager RCCL all-reduce + hipgraph(optimizer)")
-                   if use_graph else "eager (all-reduce overlapped with backward)",
+                   "parallelism": f"dp{world}", "loop": loop_desc[loop_used],
                    "weights": "random init (nn default)", "final_loss": round(final_loss, 5)},
+        "ms_per_step_event_median": round(ev_ms[len(ev_ms) // 2], 4),
+        "distributed": {"initialized": bool(ddp), "world_size": dist.get_world_size() if ddp else 1,
+                        "backend": dist.get_backend() if ddp else None,
+                        "ddp": ({"buckets": len(net.buckets), "bucket_mb": [round(b.flat.numel() * 4 / 2 ** 20, 2)
+                                                                           for b in net.buckets], **net.stats}
+                                if ddp else None)},
         "step_fraction_of_mfma_bound": round((TRAIN_GFLOP_PER_IMG * args.batch / 1e3 / PEAK_BF16_TFLOPS) / (ms / 1e3), 4)
         if args.model == "UNet" and args.size == 256 else None,
     }
 
     # ---- roofline leg: event-time every MFMA kernel launch over a few eager steps on this stream
-    if not args.no_roofline and rank == 0:
+    # (every rank runs the steps -- they contain collectives -- rank 0 reports)
+    if not args.no_roofline:
         ops.PROFILE = []
         nprof = 3
         for _ in range(nprof):
+            if split:
+                net.broadcast_buffers_now()
             step()
         torch.cuda.synchronize()
+    if not args.no_roofline and rank == 0:
         agg = {}
         for key, flops, e0, e1 in ops.PROFILE:
             a = agg.setdefault(key, [0, 0.0, 0.0])

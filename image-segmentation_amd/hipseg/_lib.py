@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("HIPSEG_LIB") or os.path.join(HERE, "lib", "libhipseg.
 
 F32, BF16 = 0, 1
 CONV3, CONV1, CONV2S2, CONVT = 0, 1, 2, 3
+AUG_NPARAM = 16  # HIPSEG_AUG_NPARAM
 
 P = c_void_p
 I = c_int
@@ -66,12 +67,14 @@ PROTOTYPES = {
     "hipseg_nchw_to_nhwc": (I, [I, P, P, I, I, I, I, P]),
     "hipseg_nhwc_to_nchw": (I, [I, P, P, I, I, I, I, P]),
     "hipseg_decode_records": (I, [P, P, P, P, P, I, I, I, P]),
+    "hipseg_augment_workspace_elems": (c_size_t, [I]),
+    "hipseg_augment": (I, [P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
 }
 
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
-         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size"}
+         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems"}
 
 
 def _load():

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work")
+    __slots__ = ("flat", "params", "views", "pending", "work", "arrived")
 
     def __init__(self, params, device):
         n = sum(p.numel() for p in params)
@@ -32,22 +32,31 @@ class _Bucket:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
         self.pending = len(params)
+        self.arrived = [False] * len(params)
         self.work = None
 
 
 class HipDDP(nn.Module):
-    def __init__(self, module, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0, broadcast_buffers=True,
-                 overlap=True):
-        """overlap=True : reduce each bucket from autograd hooks during backward (side stream, eager loops).
-        overlap=False: no hooks; the caller runs pack_gradients() / allreduce_packed() after backward --
-                       the form a hipGraph-captured step uses (fwd+bwd+pack in one graph, the collective
-                       eager between graphs, the optimiser in a second graph)."""
+    def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0,
+                 broadcast_buffers=True, overlap=True, force_collectives=False):
+        """device_ids : accepted for call compatibility with `DDP(model, device_ids=[rank])`
+                        (scripts/train_distributed.py:35); the module's own device is used.
+        overlap=True : reduce each bucket from autograd hooks during backward on a side HIP stream.  Works in eager
+                       loops and inside a hipGraph capture (the side-stream collectives become forked branches of
+                       the graph, joined at the end of backward).
+        overlap=False: no hooks; the caller runs pack_gradients() / allreduce_packed() after backward
+                       (split-graph form: fwd+bwd+pack in one graph, the collective eager, the optimiser in a second).
+        force_collectives : issue every collective even when the group has ONE rank (RCCL runs them as device-side
+                       no-op/copies), so the whole hook -> bucket -> event -> side-stream all-reduce -> join path can
+                       be rehearsed and tested on a single-GPU box."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        self.active = self.world > 1 or bool(force_collectives)
+        self.stats = {"buckets_reduced": 0, "comm_stream_collectives": 0, "hook_calls": 0, "zero_filled_slots": 0}
         self.broadcast_buffers = broadcast_buffers
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
@@ -93,9 +102,16 @@ class HipDDP(nn.Module):
                     dist.broadcast(b, 0, group=self.pg)
         self.overlap = overlap
         self._params = params
+        self._hook_handles = []
         if overlap:
             for p in params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def remove_hooks(self):
+        """detach this reducer from the module's parameters (before wrapping the same module again)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
 
     # ------------------------------------------------------------------ helpers
     def _bcast(self, tensors):
@@ -123,14 +139,18 @@ class HipDDP(nn.Module):
 
     # ------------------------------------------------------------------ backward side
     def _hook(self, p):
-        if not self._require_sync or self.world == 1:
+        if not self._require_sync or not self.active:
             return
+        self.stats["hook_calls"] += 1
         bi, pi = self._where[p]
         b = self.buckets[bi]
         view = b.views[pi]
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)
             p.grad = view  # gradient-as-bucket-view: the optimiser reads the reduced values in place
+        if b.arrived[pi]:  # a parameter used twice in one backward fires once per accumulation pass; count it once
+            return
+        b.arrived[pi] = True
         b.pending -= 1
         if not self._cb_queued:
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
@@ -139,12 +159,14 @@ class HipDDP(nn.Module):
             self._launch(b)
 
     def _launch(self, b):
+        self.stats["buckets_reduced"] += 1
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            self.stats["comm_stream_collectives"] += 1
         else:  # gloo (CPU tests): no AVG op, no streams
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -152,7 +174,13 @@ class HipDDP(nn.Module):
         """end of backward: join the communication stream, re-arm the buckets."""
         for b in self.buckets:
             if b.pending != 0 and b.pending != len(b.params):
-                # parameters unused in this backward: reduce what we have (their slots hold stale/zero data)
+                # parameters that took no part in this backward (e.g. ClipUnet's dead bottleneck): their slots are
+                # zero-filled so no stale data is reduced, and their .grad stays None, as under torch DDP with
+                # find_unused_parameters
+                for v, p, a in zip(b.views, b.params, b.arrived):
+                    if not a:
+                        v.zero_()
+                        self.stats["zero_filled_slots"] += 1
                 self._launch(b)
             if b.work is not None:
                 if self.on_gpu:
@@ -162,21 +190,29 @@ class HipDDP(nn.Module):
                     b.flat.div_(self.world)
                 b.work = None
             b.pending = len(b.params)
+            b.arrived = [False] * len(b.params)
         self._cb_queued = False
 
     # ------------------------------------------------------------------ explicit (non-overlapped) reduction
     def pack_gradients(self):
         """copy every .grad into its flat bucket slot (multi-tensor copy: a few launches, capturable)."""
-        views = [v for b in self.buckets for v in b.views]
-        grads = [p.grad for b in self.buckets for p in b.params]
-        if any(g is None for g in grads):
-            raise RuntimeError("pack_gradients: a parameter has no gradient")
-        torch._foreach_copy_(views, grads)
+        views, grads = [], []
+        for b in self.buckets:
+            for v, p in zip(b.views, b.params):
+                if p.grad is None:
+                    v.zero_()  # unused parameter: contributes zero, keeps .grad None (see use_bucket_grads)
+                elif p.grad.data_ptr() != v.data_ptr():
+                    views.append(v)
+                    grads.append(p.grad)
+        self._had_grad = [[p.grad is not None for p in b.params] for b in self.buckets]
+        if views:
+            torch._foreach_copy_(views, grads)
 
     def allreduce_packed(self):
         """average the flat buckets over ranks on the current stream and point .grad at the reduced views."""
-        if self.world > 1:
+        if self.active:
             for b in self.buckets:
+                self.stats["buckets_reduced"] += 1
                 if self.on_gpu:
                     dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
                 else:
@@ -185,16 +221,18 @@ class HipDDP(nn.Module):
         self.use_bucket_grads()
 
     def use_bucket_grads(self):
-        for b in self.buckets:
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+        had = getattr(self, "_had_grad", None)
+        for bi, b in enumerate(self.buckets):
+            for pi, (p, v) in enumerate(zip(b.params, b.views)):
+                if had is None or had[bi][pi]:
+                    p.grad = v
 
     def reduce_gradients(self):
         self.pack_gradients()
         self.allreduce_packed()
 
     def broadcast_buffers_now(self):
-        if self.broadcast_buffers and self.world > 1 and self._flat_buffers is not None:
+        if self.broadcast_buffers and self.active and self._flat_buffers is not None:
             dist.broadcast(self._flat_buffers, 0, group=self.pg)
 
     # ------------------------------------------------------------------ forward side

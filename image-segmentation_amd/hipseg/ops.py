@@ -521,3 +521,33 @@ def confusion_matrix(logits, target):
     conf = torch.empty((C, C), dtype=torch.int64, device=logits.device)
     L.confusion(ptr(logits), ptr(target), ptr(conf), B, C, logits[0, 0].numel(), _stream())
     return conf
+
+
+def augment(images, masks, extra, params, order):
+    """hipseg_augment on the current stream: flip + nearest rotation on image||mask[||extra], colour jitter + 5x5
+    Gaussian blur on the image (models/processing_blocks.py:344-384).  images (B,3,H,W) fp32, masks (B,H,W) int64 or
+    None, extra (B,E,H,W) fp32 or None, params (B, AUG_NPARAM) fp32, order int32[4] -- all on the GPU."""
+    _require_gpu(images)
+    images = images.float().contiguous()
+    B, C, H, W = images.shape
+    if C != 3:
+        raise ValueError(f"augment: expected 3 image channels, got {C}")
+    if params.shape != (B, L.AUG_NPARAM) or params.dtype != torch.float32 or order.dtype != torch.int32:
+        raise ValueError("augment: params must be (B, AUG_NPARAM) fp32 and order int32[4]")
+    dev = images.device
+    out = torch.empty_like(images)
+    om = oe = None
+    ne = 0
+    if masks is not None:
+        masks = masks.long().contiguous()
+        if masks.shape != (B, H, W):
+            raise ValueError(f"augment: masks must be (B,H,W), got {tuple(masks.shape)}")
+        om = torch.empty_like(masks)
+    if extra is not None:
+        extra = extra.float().contiguous()
+        ne = extra.shape[1]
+        oe = torch.empty_like(extra)
+    part = _f32(L.augment_workspace_elems(B), dev)
+    L.augment(ptr(images), ptr(masks), ptr(extra), ne, ptr(params.contiguous()), ptr(order.contiguous()), ptr(part),
+              ptr(out), ptr(om), ptr(oe), B, H, W, _stream())
+    return out, om, oe

@@ -6,7 +6,6 @@ from models.processing_blocks import (ClipFeatureExtractor, ConvBlock, ConvBlock
                                       ConvBlockUpsampleSkip, CrossAttentionFusion)
 from models.UNet import UNet
 
-__all__ = ["ClipUnet"]
 
 
 class ClipUnet(UNet):

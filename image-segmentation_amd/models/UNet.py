@@ -5,7 +5,6 @@ import torch.nn as nn
 from hipseg import ops
 from models.processing_blocks import ConvBlock, ConvBlockDownsample, ConvBlockUpsampleSkip
 
-__all__ = ["UNet", "LargeUNet"]
 
 
 def _stem(conv, x):

@@ -4,8 +4,6 @@ import torch.nn as nn
 
 from hipseg import ops
 
-__all__ = ["HybridLoss", "HybridLossBinary", "IoU", "IoUBinary", "PixelAccuracy", "PixelAccuracyBinary",
-           "CombinedConfusionLoss"]
 
 
 class HybridLoss(nn.Module):
@@ -89,14 +87,68 @@ class PixelAccuracyBinary(nn.Module):
         return (p == t).float().sum() / t.numel()
 
 
-class CombinedConfusionLoss(nn.Module):
-    """Constructed by the reference's HybridLoss but never used in its forward (losses.py:11,182-214);
-    kept as a name for import compatibility."""
+def _soft_dice_score(p, t, dims, smooth=0.0, eps=1e-7):
+    """smp 0.4.0 `soft_dice_score`: (2*sum(p*t) + smooth) / clamp_min(sum(p + t) + smooth, eps) over `dims`."""
+    inter = (p * t).sum(dims)
+    card = (p + t).sum(dims)
+    return (2.0 * inter + smooth) / (card + smooth).clamp_min(eps)
 
-    def __init__(self, incorrect_penalty=2.0, confusion_pairs=((1, 2),), confusion_penalty=2.0):
+
+class Dice(nn.Module):
+    """1 - smp.losses.DiceLoss(mode='multiclass')(softmax(preds), targets) (reference: losses.py:92-100).
+
+    smp 0.4.0 (absent third-party arithmetic -- PARITY UNPINNED, restated from its published algorithm, see
+    DESIGN.md): `from_logits=True` applies log_softmax(dim=1).exp() to its input again, so the score is computed on
+    softmax(softmax(preds)); per-class soft dice over dims (batch, pixels) with smooth 0 / eps 1e-7, classes absent
+    from the target contribute loss 0, mean over classes.  Validation-only metric (the wrappers construct it and
+    then report 2*IoU/(1+IoU) instead, model_wrappers.py:151,211): evaluated with elementwise torch ops."""
+
+    def __init__(self, eps=1e-6):
         super().__init__()
-        self.incorrect_penalty, self.confusion_pairs, self.confusion_penalty = (incorrect_penalty, confusion_pairs,
-                                                                                confusion_penalty)
+
+    def forward(self, preds, targets):
+        B, C = preds.shape[0], preds.shape[1]
+        p = torch.softmax(torch.softmax(preds.float(), dim=1), dim=1).reshape(B, C, -1)
+        t = torch.nn.functional.one_hot(targets.reshape(B, -1).long(), C).permute(0, 2, 1).to(p.dtype)
+        score = _soft_dice_score(p, t, (0, 2))
+        loss = (1.0 - score) * (t.sum((0, 2)) > 0).to(p.dtype)
+        return 1.0 - loss.mean()
+
+
+class DiceBinary(nn.Module):
+    """1 - smp.losses.DiceLoss(mode='binary')(sigmoid(preds), targets) (reference: losses.py:102-126); same smp
+    semantics as the Dice term of HybridLossBinary (sigmoid applied twice), PARITY UNPINNED."""
+
+    def __init__(self, eps=1e-6, threshold=0.5):
+        super().__init__()
+        self.eps, self.threshold = eps, threshold
+
+    def forward(self, preds, targets):
+        B = preds.shape[0]
+        t = (targets.unsqueeze(1) if targets.dim() == 3 else targets).float().reshape(B, 1, -1)
+        p = torch.sigmoid(torch.sigmoid(preds.float())).reshape(B, 1, -1)
+        score = _soft_dice_score(p, t, (0, 2))
+        loss = (1.0 - score) * (t.sum((0, 2)) > 0).to(p.dtype)
+        return 1.0 - loss.mean()
+
+
+class CombinedConfusionLoss(nn.Module):
+    """Per-pixel cross-entropy, x incorrect_penalty where argmax != target, x confusion_penalty again where the
+    (prediction, target) pair is one of `confusion_pairs` in either order; mean (reference: losses.py:182-214).
+    Constructed by the reference's HybridLoss but never used in its forward; off the hot path, elementwise torch ops."""
+
+    def __init__(self, incorrect_penalty=2.0, confusion_pairs=[(1, 2)], confusion_penalty=2.0):  # noqa: B006
+        super().__init__()
+        self.incorrect_penalty = incorrect_penalty
+        self.confusion_pairs = confusion_pairs
+        self.confusion_penalty = confusion_penalty
 
     def forward(self, pred, target):
-        raise NotImplementedError("CombinedConfusionLoss is off the training hot path (unused by HybridLoss.forward)")
+        pred = pred.float()
+        loss = torch.nn.functional.cross_entropy(pred, target, reduction="none")
+        cls = torch.softmax(pred, dim=1).argmax(dim=1)
+        w = torch.where(cls != target, self.incorrect_penalty, 1.0)
+        for c1, c2 in self.confusion_pairs:
+            conf = ((cls == c1) & (target == c2)) | ((cls == c2) & (target == c1))
+            w = torch.where(conf, w * self.confusion_penalty, w)
+        return (loss * w).mean()

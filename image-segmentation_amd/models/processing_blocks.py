@@ -5,13 +5,16 @@ modules the reference's state_dict keys, default initialisation and the attribut
 models/helperFunctions.py:45-78 introspects.  forward() never calls them; it runs the fused HIP
 pipeline in hipseg.ops on NHWC activations.
 """
+import math
+import random
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+from torch import cat  # noqa: F401  (the reference module exports `cat`; star-importers may use it)
 
 from hipseg import ops
 
-__all__ = ["ConvBlock", "ConvBlockDownsample", "ConvBlockUpsampleSkip", "ConvBlockUpsample",
-           "CrossAttentionFusion", "CustomClipPreprocessor", "ClipFeatureExtractor"]
 
 
 def _double_conv(seq, x, skip, pool):
@@ -175,3 +178,180 @@ class ClipFeatureExtractor(nn.Module):
         with torch.set_grad_enabled(self.train_clip):
             feats = self.clip_model.get_image_features(pixel_values=inputs)
         return feats if torch.is_tensor(feats) else feats.pooler_output
+
+
+class ResNet34FeatureExtractor(nn.Module):
+    """ImageNet ResNet-34 trunk without avgpool/fc, optionally frozen (reference: processing_blocks.py:236-285).
+    Off the hot path (used by ClipResSegmentationModel only) and a torchvision model: kept on PyTorch-ROCm.  Raises a
+    clear ImportError when torchvision is not installed instead of failing at module import."""
+
+    def __init__(self, train=False):
+        super().__init__()
+        try:
+            import torchvision.models as tvm
+        except ImportError as e:  # pragma: no cover - depends on the environment
+            raise ImportError("ResNet34FeatureExtractor needs torchvision (reference: processing_blocks.py:262 "
+                              "`models.resnet34(weights='IMAGENET1K_V1')`)") from e
+        resnet = tvm.resnet34(weights="IMAGENET1K_V1")
+        self.model = nn.Sequential(*list(resnet.children())[:-2])
+        self.set_train(train)
+        self.train_res = train
+
+    def set_train(self, value: bool):
+        assert isinstance(value, bool), "Value must be a boolean"
+        for p in self.model.parameters():
+            p.requires_grad = value
+        self.train_res = value
+
+    def forward(self, X):
+        with torch.set_grad_enabled(self.train_res):
+            return self.model(X)
+
+
+# ------------------------------------------------------------------------------------------------
+# On-device augmentation (reference: processing_blocks.py:324-451).  The reference composes kornia modules; here the
+# host only SAMPLES the random parameters (torch RNG on the device, no host sync) and one fused HIP pipeline
+# (csrc/augment.hip) applies flip + rotation to image||mask[||prompt] and colour jitter + blur to the image.
+# kornia 0.8.0 is absent: parameter ranges / probabilities follow its documented defaults, PARITY UNPINNED.
+class _AugmentorBase(nn.Module):
+    flip_p = 0.5            # K.RandomHorizontalFlip() default p
+    rotate_p = 0.5          # K.RandomRotation default p
+    degrees = 90.0          # K.RandomRotation(90): angle ~ U[-90, 90]
+    brightness = 0.4        # K.ColorJitter(brightness=0.4): factor ~ U[0.6, 1.4]
+    contrast = 0.3          # factor ~ U[0.7, 1.3]
+    saturation = 0.2        # factor ~ U[0.8, 1.2]
+    hue = 0.2               # shift ~ U[-0.2, 0.2] turns
+    sigma = (0.1, 2.0)      # K.RandomGaussianBlur(kernel_size=(5,5), sigma=(0.1, 2.0), p=1.0)
+
+    def __init__(self, augmentations_per_datapoint):
+        super().__init__()
+        self.augmentations_per_datapoint = augmentations_per_datapoint
+        self.last_params = None  # (params, order) of the most recent call: lets tests replay it on the CPU oracle
+
+    def sample_params(self, B, device):
+        """(B, AUG_NPARAM) fp32 table + int32[4] op order, sampled on `device` (see include/hipseg.h)."""
+        from hipseg import _lib as L
+
+        u = torch.rand(B, 8, device=device)
+        p = torch.zeros(B, L.AUG_NPARAM, device=device)
+        idx = torch.arange(B, device=device)
+        p[:, 0] = (idx % (self.augmentations_per_datapoint + 1) == 0).float()
+        p[:, 1] = (u[:, 0] < self.flip_p).float()
+        theta = torch.deg2rad((u[:, 2] * 2.0 - 1.0) * self.degrees) * (u[:, 1] < self.rotate_p).float()
+        p[:, 2], p[:, 3] = torch.cos(theta), torch.sin(theta)
+        p[:, 4] = 1.0 + (u[:, 3] * 2.0 - 1.0) * self.brightness
+        p[:, 5] = 1.0 + (u[:, 4] * 2.0 - 1.0) * self.contrast
+        p[:, 6] = 1.0 + (u[:, 5] * 2.0 - 1.0) * self.saturation
+        p[:, 7] = (u[:, 6] * 2.0 - 1.0) * self.hue * (2.0 * math.pi)
+        p[:, 8] = self.sigma[0] + u[:, 7] * (self.sigma[1] - self.sigma[0])
+        order = torch.randperm(4, device=device).to(torch.int32)
+        return p, order
+
+
+class DataAugmentor(_AugmentorBase):
+    """forward(images (B,3,H,W), masks (B,H,W)) -> (images, masks.long()); every (aug+1)-th sample untouched
+    (reference: processing_blocks.py:324-384)."""
+
+    @torch.no_grad()
+    def forward(self, images, masks):
+        params, order = self.sample_params(images.shape[0], images.device)
+        self.last_params = (params, order)
+        out, om, _ = ops.augment(images, masks, None, params, order)
+        return out, om
+
+
+class DataAugmentorPrompt(_AugmentorBase):
+    """forward(images, masks (B,H,W) or (B,1,H,W), prompts (B,1,H,W)) -> (images, masks (B,H,W) long, prompts)
+    (reference: processing_blocks.py:386-451)."""
+
+    @torch.no_grad()
+    def forward(self, images, masks, prompts):
+        if masks.dim() == 4:
+            masks = masks[:, 0]
+        if prompts.dim() == 3:
+            prompts = prompts.unsqueeze(1)
+        params, order = self.sample_params(images.shape[0], images.device)
+        self.last_params = (params, order)
+        out, om, oe = ops.augment(images, masks, prompts, params, order)
+        return out, om, oe
+
+
+# ------------------------------------------------------------------------------------------------
+# Robustness perturbations of TestWrapper.test_robustness (reference: processing_blocks.py:454-592,
+# model_wrappers.py:740-764).  Test-time only, a few elementwise passes per evaluation batch: plain torch ops.
+class GaussianPixelNoise(nn.Module):
+    """img + N(0, (std/255)^2), clamped to [0,1] (reference :454-474)."""
+
+    def __init__(self, std):
+        super().__init__()
+        self.std = std
+
+    def forward(self, img):
+        return torch.clamp(img + torch.randn_like(img) * (self.std / 255.0), 0.0, 1.0)
+
+
+class RepeatedBlur(nn.Module):
+    """`times` x 3x3 box blur (reference :477-496 uses kornia.filters.box_blur: normalised, reflect border)."""
+
+    def __init__(self, times):
+        super().__init__()
+        self.times = times
+
+    def forward(self, img):
+        for _ in range(self.times):
+            img = F.avg_pool2d(F.pad(img, (1, 1, 1, 1), mode="reflect"), kernel_size=3, stride=1)
+        return img
+
+
+class ContrastChange(nn.Module):
+    """img * factor, clamped (reference :499-518)."""
+
+    def __init__(self, factor):
+        super().__init__()
+        self.factor = factor
+
+    def forward(self, img):
+        return torch.clamp(img * self.factor, 0.0, 1.0)
+
+
+class BrightnessChange(nn.Module):
+    """img + offset/255, clamped (reference :521-539)."""
+
+    def __init__(self, offset):
+        super().__init__()
+        self.offset = offset / 255.0
+
+    def forward(self, img):
+        return torch.clamp(img + self.offset, 0.0, 1.0)
+
+
+class Occlusion(nn.Module):
+    """zero one random size x size square per image, IN PLACE as the reference does (reference :542-563; positions
+    from Python's `random`, so `random.seed` reproduces the reference's squares)."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size = size
+
+    def forward(self, img):
+        b, c, h, w = img.shape
+        for i in range(b):
+            x = random.randint(0, w - self.size) if w > self.size else 0
+            y = random.randint(0, h - self.size) if h > self.size else 0
+            img[i, :, y:y + self.size, x:x + self.size] = 0.0
+        return img
+
+
+class SaltAndPepper(nn.Module):
+    """one uniform draw per pixel: < amount/2 -> salt (1), > 1 - amount/2 -> pepper (0) (reference :565-592)."""
+
+    def __init__(self, amount):
+        super().__init__()
+        self.amount = amount
+
+    def forward(self, img):
+        b, c, h, w = img.shape
+        noise = torch.rand((b, 1, h, w), device=img.device)
+        salt = (noise < self.amount / 2).float()
+        pepper = (noise > 1 - self.amount / 2).float()
+        return img * (1 - salt - pepper) + salt

@@ -229,6 +229,22 @@ int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H,
 int hipseg_decode_records(const uint8_t* images, const uint8_t* masks, float* out_images, int64_t* out_masks,
                           int* cat_flags, int n, int H, int W, hipseg_stream_t stream);
 
+/* ---- on-device training augmentation (the per-step caller in front of the path) -------------------
+ * replaces: DataAugmentor.forward / DataAugmentorPrompt.forward, models/processing_blocks.py:344-384,386-451 (kornia
+ * RandomHorizontalFlip + RandomRotation(90, nearest) on image||mask[||prompt], ColorJitter + RandomGaussianBlur(5x5) on
+ * the image; called every step at models/model_wrappers.py:165,968).  kornia 0.8.0's arithmetic: PARITY UNPINNED.
+ * images (B,3,H,W) fp32 NCHW in [0,1]; masks (B,H,W) int64 or NULL; extra (B,n_extra,H,W) fp32 geometric-only
+ * channels or NULL.  params: B rows of HIPSEG_AUG_NPARAM floats:
+ *   [0] keep (!=0: sample copied through untouched)  [1] flip (!=0)  [2] cos, [3] sin of the rotation angle
+ *   [4] brightness factor  [5] contrast factor  [6] saturation factor  [7] hue shift (radians)  [8] blur sigma
+ * order: int[4], a permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue} (one per call).
+ * partial: fp32 workspace of hipseg_augment_workspace_elems(B).  Outputs must not alias inputs. */
+#define HIPSEG_AUG_NPARAM 16
+size_t hipseg_augment_workspace_elems(int B);
+int hipseg_augment(const float* images, const int64_t* masks, const float* extra, int n_extra,
+                   const float* params, const int* order, float* partial, float* out_images,
+                   int64_t* out_masks, float* out_extra, int B, int H, int W, hipseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

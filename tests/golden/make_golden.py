@@ -36,7 +36,8 @@ import torch.nn as nn  # noqa: E402
 from models.UNet import UNet, LargeUNet  # noqa: E402  (reference)
 from models.processing_blocks import (ConvBlock, ConvBlockDownsample, ConvBlockUpsampleSkip,  # noqa: E402
                                       ConvBlockUpsample, CrossAttentionFusion)
-from models.losses import HybridLoss, IoU, IoUBinary, PixelAccuracy, PixelAccuracyBinary  # noqa: E402
+from models.losses import (HybridLoss, IoU, IoUBinary, PixelAccuracy, PixelAccuracyBinary,  # noqa: E402
+                           CombinedConfusionLoss)
 import models.CLIP_models as ref_clip  # noqa: E402
 
 from oracle import fill  # noqa: E402
@@ -261,12 +262,91 @@ def gen_records():
     print("records.npz", len(out))
 
 
+# ------------------------------------------------------------------ round-2 fixtures (separate files: the round-1 ones stay)
+TRAINED_PREFIXES = ("dec4.", "out.")  # the parameters the reference trains for the confident-logits fixture
+
+
+def blob_task(tag, n, size=64, cells=8):
+    """Learnable synthetic segmentation task: smooth random colour fields (cells x cells uniform noise, bilinearly
+    up-sampled to size x size); the class of a pixel is its brightest channel.  Pure function of (tag, n, size)."""
+    low = T(f"{tag}.low", (n, 3, cells, cells))
+    x = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=True)
+    x = (x - x.amin((1, 2, 3), keepdim=True)) / (x.amax((1, 2, 3), keepdim=True) - x.amin((1, 2, 3), keepdim=True))
+    return x.contiguous(), x.argmax(1)
+
+
+def gen_round2():
+    out = {}
+    # (1) LargeUNet at a size that reaches the 1024-channel layers with H = 8 > the 4x4 of large_64
+    x = T("large128.x", (1, 3, 128, 128))
+    t = torch.from_numpy(fill.randint("large128.t", (1, 128, 128), 3))
+    _model_case(out, "large_128", LargeUNet(), x, t, grad_keys=("input.weight", "out.weight", "bottleneck.conv.3.bias"))
+    # (2) reference-TRAINED confident logits: the reference UNet with oracle.fill weights, its last decoder block and
+    # head (dec4.*, out.*: 36 K parameters, small enough to commit) trained by the reference's own loop body
+    # (models/model_wrappers.py:167-177, fp32) on the blob task; every BatchNorm's running statistics move too.
+    # The fp32 logits/masks of the trained reference on held-out images are what the bf16 HIP path must reproduce
+    # within 1e-2 IoU (north star) -- margins here are far above bf16 noise, unlike the untrained unet_c1 fixture.
+    m = UNet()
+    fill.fill_state_dict(m.state_dict())
+    for k, p in m.named_parameters():
+        p.requires_grad_(k.startswith(TRAINED_PREFIXES))
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=3e-3, weight_decay=1e-4)
+    xtr, ttr = blob_task("blob.train", 4)
+    crit = HybridLoss()
+    m.train()
+    traj = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = crit(m(xtr), ttr)
+        loss.backward()
+        opt.step()
+        traj.append(float(loss))
+    out["trained/loss_traj"] = np.array(traj)
+    for k, v in m.state_dict().items():
+        if k.startswith(TRAINED_PREFIXES) or k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            out[f"trained/state/{k}"] = npy(v)
+    xte, tte = blob_task("blob.test", 4)
+    m.eval()
+    with torch.no_grad():
+        lg = m(xte)
+    out["trained/eval_logits"] = npy(lg)
+    out["trained/target"] = npy(tte).astype(np.uint8)
+    top2 = lg.topk(2, dim=1).values
+    out["trained/median_margin"] = npy((top2[:, 0] - top2[:, 1]).median())
+    out["trained/iou_vs_target"] = npy(IoU()(lg, tte))
+    saved = {k: v.clone() for k, v in m.state_dict().items()}
+    m.train()
+    with torch.no_grad():
+        out["trained/train_logits"] = npy(m(xte))
+    m.load_state_dict(saved)
+    np.savez_compressed(os.path.join(HERE, "models_r2.npz"), **out)
+    print("models_r2.npz", len(out), "final loss", traj[-1], "median margin", float(out["trained/median_margin"]),
+          "IoU vs target", float(out["trained/iou_vs_target"]))
+    # (3) CombinedConfusionLoss (models/losses.py:182-214), value and gradient
+    lo = {}
+    logits = T("loss.logits", (2, 3, 32, 32), -3.0, 3.0)
+    tgt = torch.from_numpy(fill.randint("loss.t", (2, 32, 32), 3))
+    for tag, kw in (("default", {}), ("pairs", {"incorrect_penalty": 1.5, "confusion_pairs": [(0, 1), (1, 2)],
+                                                "confusion_penalty": 3.0})):
+        lg = logits.clone().requires_grad_(True)
+        v = CombinedConfusionLoss(**kw)(lg, tgt)
+        v.backward()
+        lo[f"ccl_{tag}"] = npy(v)
+        lo[f"ccl_{tag}_grad"] = npy(lg.grad)
+    np.savez_compressed(os.path.join(HERE, "losses_r2.npz"), **lo)
+    print("losses_r2.npz", len(lo))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "records":  # regenerate one fixture file only
         gen_records()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        gen_round2()
         sys.exit(0)
     gen_blocks()
     gen_models()
     gen_clip()
     gen_losses()
     gen_records()
+    gen_round2()

@@ -195,6 +195,30 @@ for p, g in zip(net3.parameters(), local):
     ref = g.clone(); dist.all_reduce(ref); ref /= world
     assert torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-8)
     assert any(p.grad.data_ptr() == v.data_ptr() for b in ddp3.buckets for v in b.views)
+# a parameter that takes no part in backward (ClipUnet's dead bottleneck): zero-filled slot, .grad stays None
+class Unused(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(4, 4); self.dead = nn.Linear(4, 4); self.b = nn.Linear(4, 2)
+    def forward(self, x):
+        return self.b(self.a(x))
+for overlap in (True, False):
+    torch.manual_seed(5)
+    net4 = Unused()
+    ddp4 = HipDDP(net4, overlap=overlap, bucket_cap_mb=1.0, first_bucket_mb=1.0)   # one bucket holds all three
+    assert len(ddp4.buckets) == 1
+    ddp4.buckets[0].flat.fill_(123.0)                # stale garbage must not be reduced
+    xr = torch.full((3, 4), float(rank + 1))
+    ddp4(xr).sum().backward()
+    if not overlap:
+        ddp4.reduce_gradients()
+    assert net4.dead.weight.grad is None and net4.dead.bias.grad is None
+    bi, pi = ddp4._where[net4.dead.weight]
+    assert float(ddp4.buckets[bi].views[pi].abs().max()) == 0.0
+    exp = sum(float(r + 1) for r in range(world)) / world * 3
+    assert torch.allclose(net4.b.bias.grad, torch.full((2,), 3.0)), net4.b.bias.grad
+    assert torch.allclose(net4.a.bias.grad, (net4.b.weight.sum(0) * 3).detach())
+    ddp4.remove_hooks()
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 """
@@ -210,3 +234,88 @@ def test_hipddp_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]
+
+
+def test_off_path_losses_and_perturbations(L, golden):
+    """The names the reference's callers import that are OFF the kernel path (plain torch ops, CPU-runnable):
+    CombinedConfusionLoss against the reference's own outputs (tests/golden/losses_r2.npz), Dice / DiceBinary against
+    hand-derived known answers (smp 0.4.0 absent: parity unpinned), the robustness perturbations against their
+    definitions (models/processing_blocks.py:454-592)."""
+    import random
+
+    from models import losses as ls, processing_blocks as pb
+    from oracle import fill
+
+    g = golden("losses_r2")
+    logits = torch.from_numpy(fill.uniform("loss.logits", (2, 3, 32, 32), -3.0, 3.0))
+    tgt = torch.from_numpy(fill.randint("loss.t", (2, 32, 32), 3))
+    for tag, kw in (("default", {}), ("pairs", {"incorrect_penalty": 1.5, "confusion_pairs": [(0, 1), (1, 2)],
+                                                "confusion_penalty": 3.0})):
+        lg = logits.clone().requires_grad_(True)
+        v = ls.CombinedConfusionLoss(**kw)(lg, tgt)
+        v.backward()
+        assert abs(float(v) - float(g[f"ccl_{tag}"])) <= 1e-6
+        np.testing.assert_allclose(lg.grad.numpy(), g[f"ccl_{tag}_grad"], rtol=1e-5, atol=1e-9)
+    # Dice: uniform logits -> softmax(softmax) = 1/3; target all class 0 -> dice_0 = (2/3)/(4/3), absent classes
+    # contribute 0 loss -> score = 1 - mean([1/2, 0, 0]) = 5/6
+    z = torch.zeros(2, 3, 4, 4)
+    assert abs(float(ls.Dice()(z, torch.zeros(2, 4, 4, dtype=torch.long))) - 5.0 / 6.0) < 1e-6
+    # DiceBinary: zero logits, all-ones target: p = sigmoid(sigmoid(0)) = sigmoid(.5); score = 2p/(p+1)
+    s = 1 / (1 + np.exp(-0.5))
+    assert abs(float(ls.DiceBinary()(torch.zeros(2, 1, 4, 4), torch.ones(2, 4, 4))) - 2 * s / (s + 1)) < 1e-6
+    assert float(ls.DiceBinary()(torch.zeros(2, 1, 4, 4), torch.zeros(2, 4, 4))) == 1.0  # empty target: loss masked
+    # perturbations
+    img = torch.rand(2, 3, 12, 12)
+    assert torch.equal(pb.ContrastChange(1.5)(img), (img * 1.5).clamp(0, 1))
+    assert torch.equal(pb.BrightnessChange(30)(img), (img + 30 / 255.0).clamp(0, 1))
+    n = pb.GaussianPixelNoise(10)(img)
+    assert n.shape == img.shape and float(n.min()) >= 0 and float(n.max()) <= 1 and not torch.equal(n, img)
+    blur = pb.RepeatedBlur(1)(img)
+    assert abs(float(blur[0, 0, 5, 5]) - float(img[0, 0, 4:7, 4:7].mean())) < 1e-6
+    corner = (img[0, 0, 0, 0] + 2 * img[0, 0, 0, 1] + 2 * img[0, 0, 1, 0] + 4 * img[0, 0, 1, 1]) / 9  # reflect border
+    assert abs(float(blur[0, 0, 0, 0]) - float(corner)) < 1e-6
+    assert pb.RepeatedBlur(3)(img).shape == img.shape
+    random.seed(4)
+    occ = pb.Occlusion(5)(img.clone())
+    assert all(int((occ[i] == 0).all(0).sum()) >= 25 for i in range(2))
+    sp = pb.SaltAndPepper(0.5)(img)
+    frac = float(((sp == 1).all(1) | (sp == 0).all(1)).float().mean())
+    assert 0.3 < frac < 0.7
+    with pytest.raises(ImportError, match="torchvision"):
+        pb.ResNet34FeatureExtractor()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pb.DataAugmentor(4)(img, torch.zeros(2, 12, 12, dtype=torch.long))
+
+
+def test_augment_oracle_exact_parts():
+    """oracle/augment.py (the checker of the HIP augmentation kernels; kornia arithmetic, PARITY UNPINNED): the parts
+    that have exact answers -- identity parameters, pure flip, kept samples, a 90-degree turn, hue full-turn,
+    normalised blur taps."""
+    import math
+
+    from oracle import augment as A
+
+    torch.manual_seed(0)
+    B, H, W = 4, 12, 12
+    img = torch.rand(B, 3, H, W)
+    msk = torch.randint(0, 3, (B, H, W))
+    p = torch.zeros(B, 16)
+    p[:, 2] = 1.0                      # cos = 1: no rotation
+    p[:, 4:7] = 1.0                    # unit colour factors
+    p[:, 8] = 1e-3                     # sigma -> 0: blur is the identity
+    p[0, 0] = 1.0                      # sample 0 kept
+    p[1, 1] = 1.0                      # sample 1 flipped
+    p[2, 2], p[2, 3] = 0.0, 1.0        # sample 2 turned by 90 degrees
+    p[3, 7] = 2 * math.pi              # sample 3: hue shifted by a full turn
+    out, om, _ = A.augment(img, msk, None, p, [0, 1, 2, 3])
+    assert torch.equal(out[0], img[0]) and torch.equal(om[0], msk[0])
+    np.testing.assert_allclose(out[1].numpy(), img[1].flip(-1).numpy(), atol=1e-6)
+    assert torch.equal(om[1], msk[1].flip(-1))
+    turned = {tuple(torch.rot90(msk[2], k).reshape(-1).tolist()) for k in (1, 3)}
+    assert tuple(om[2].reshape(-1).tolist()) in turned  # a quarter turn (direction = kornia's sign convention)
+    np.testing.assert_allclose(out[3].numpy(), img[3].numpy(), atol=2e-6)
+    # a real blur preserves the mean of a constant image and the label set is preserved by the geometry
+    p[1, 8] = 1.5
+    out2, om2, _ = A.augment(torch.full((B, 3, H, W), 0.25), msk, None, p, [3, 2, 1, 0])
+    np.testing.assert_allclose(out2[1].numpy(), 0.25, atol=1e-6)
+    assert set(om2.unique().tolist()) <= {0, 1, 2}
