@@ -11,14 +11,24 @@ import torch
 PREFIXES = ("_orig_mod.", "module.")
 
 
+def _strip_key(k):
+    """`module.` (DDP) is only ever a LEADING prefix, possibly interleaved with `_orig_mod.` (compile inside/outside
+    DDP); `_orig_mod.` is removed as a dot-delimited path component anywhere (model_wrappers.py:326-329 uses
+    `k.replace("_orig_mod.", "")`).  A submodule whose name merely ENDS in "module" (`fusion_module.weight`) is kept."""
+    changed = True
+    while changed:
+        changed = False
+        for p in PREFIXES:
+            if k.startswith(p):
+                k, changed = k[len(p):], True
+    return ".".join(c for c in k.split(".") if c != "_orig_mod")
+
+
 def strip_wrapper_prefixes(state_dict):
-    """Remove every `_orig_mod.` / `module.` wrapper prefix occurrence (model_wrappers.py:326-329 uses
-    `k.replace("_orig_mod.", "")`, i.e. anywhere in the key; DDP adds `module.` in front)."""
+    """Remove the `_orig_mod.` / `module.` wrapper prefixes of a reference-format checkpoint."""
     out = OrderedDict()
     for k, v in state_dict.items():
-        nk = k
-        for p in PREFIXES:
-            nk = nk.replace(p, "")
+        nk = _strip_key(k)
         if nk in out:
             raise KeyError(f"hipseg.ckpt: keys collide after prefix removal: {k!r} -> {nk!r}")
         out[nk] = v

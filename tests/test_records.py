@@ -51,6 +51,10 @@ def test_ckpt_prefix_roundtrip():
             assert all(torch.equal(a, b) for a, b in zip(other.state_dict().values(), sd.values()))
     with pytest.raises(KeyError):
         ck.strip_wrapper_prefixes({"module.a": 1, "a": 2})
+    # `module.` is a leading prefix only: a submodule whose name ends in "module" is not mangled
+    got = ck.strip_wrapper_prefixes({"module._orig_mod.fusion_module.weight": 1, "_orig_mod.module.x.module.y": 2,
+                                     "enc._orig_mod.z": 3})
+    assert list(got) == ["fusion_module.weight", "x.module.y", "enc.z"]
 
 
 def test_decode_host_validation():
