@@ -38,7 +38,7 @@ class _Bucket:
 
 class HipDDP(nn.Module):
     def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0,
-                 broadcast_buffers=True, overlap=True, force_collectives=False):
+                 broadcast_buffers=True, overlap=True, force_collectives=False, grad_in_bucket=True):
         """device_ids : accepted for call compatibility with `DDP(model, device_ids=[rank])`
                         (scripts/train_distributed.py:35); the module's own device is used.
         overlap=True : reduce each bucket from autograd hooks during backward on a side HIP stream.  Works in eager
@@ -48,7 +48,8 @@ class HipDDP(nn.Module):
                        (split-graph form: fwd+bwd+pack in one graph, the collective eager, the optimiser in a second).
         force_collectives : issue every collective even when the group has ONE rank (RCCL runs them as device-side
                        no-op/copies), so the whole hook -> bucket -> event -> side-stream all-reduce -> join path can
-                       be rehearsed and tested on a single-GPU box."""
+                       be rehearsed and tested on a single-GPU box.
+        grad_in_bucket : let the HIP backward kernels write parameter gradients directly into the bucket slots."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
@@ -56,7 +57,8 @@ class HipDDP(nn.Module):
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.active = self.world > 1 or bool(force_collectives)
-        self.stats = {"buckets_reduced": 0, "comm_stream_collectives": 0, "hook_calls": 0, "zero_filled_slots": 0}
+        self.stats = {"buckets_reduced": 0, "comm_stream_collectives": 0, "hook_calls": 0, "hook_copies": 0,
+                      "zero_filled_slots": 0}
         self.broadcast_buffers = broadcast_buffers
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
@@ -106,12 +108,27 @@ class HipDDP(nn.Module):
         if overlap:
             for p in params:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
+        # gradient-as-bucket-view from the source: the HIP backward kernels write each parameter gradient straight into
+        # its bucket slot (hipseg.ops.grad_out), so neither the hooks nor pack_gradients() move any data for them
+        self._slotted = []
+        if self.on_gpu and grad_in_bucket:
+            for b in self.buckets:
+                o = 0
+                for p in b.params:
+                    p._hipseg_slot = (b.flat, o)
+                    self._slotted.append(p)
+                    o += p.numel()
 
     def remove_hooks(self):
         """detach this reducer from the module's parameters (before wrapping the same module again)."""
         for h in self._hook_handles:
             h.remove()
         self._hook_handles = []
+        for p in self._slotted:
+            slot = getattr(p, "_hipseg_slot", None)
+            if slot is not None and any(slot[0] is b.flat for b in self.buckets):  # (a later reducer may own it now)
+                del p._hipseg_slot
+        self._slotted = []
 
     # ------------------------------------------------------------------ helpers
     def _bcast(self, tensors):
@@ -146,7 +163,8 @@ class HipDDP(nn.Module):
         b = self.buckets[bi]
         view = b.views[pi]
         if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
+            view.copy_(p.grad)  # (gradients not produced by the HIP kernels, or accumulated ones)
+            self.stats["hook_copies"] += 1
             p.grad = view  # gradient-as-bucket-view: the optimiser reads the reduced values in place
         if b.arrived[pi]:  # a parameter used twice in one backward fires once per accumulation pass; count it once
             return

@@ -83,6 +83,28 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+# ---- gradient destinations.  HipDDP attaches to each parameter the slot of its flat fp32 reduction bucket
+# (`p._hipseg_slot = (flat bucket, element offset)`); the backward kernels then write parameter gradients STRAIGHT into
+# the bucket (a fresh view per backward, so autograd's AccumulateGrad adopts it without a copy) and the reducer's hooks
+# have nothing to move.  Parameters without a slot, or whose .grad is being accumulated into, get an ordinary new tensor.
+def grad_out(p):
+    s = getattr(p, "_hipseg_slot", None)
+    if s is None or p.grad is not None:
+        return torch.empty(p.shape, dtype=torch.float32, device=p.device)
+    flat, o = s
+    return flat[o:o + p.numel()].view(p.shape)
+
+
+def grad_out_pair(first, second):
+    """one contiguous fp32 tensor [first.numel() + second.numel()] that is BOTH parameters' bucket slots when they are
+    adjacent in that order (BatchNorm bias, weight: the layout bn_bwd's [sum g, sum g*xhat] vector has), else new."""
+    n1, n2 = first.numel(), second.numel()
+    a, b = getattr(first, "_hipseg_slot", None), getattr(second, "_hipseg_slot", None)
+    if a is not None and b is not None and a[0] is b[0] and a[1] + n1 == b[1] and first.grad is None and second.grad is None:
+        return a[0][a[1]:a[1] + n1 + n2]
+    return torch.empty(n1 + n2, dtype=torch.float32, device=first.device)
+
+
 # ---------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every MFMA kernel
 # launch is bracketed by HIP events on the launch stream and recorded as
@@ -270,14 +292,15 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     return raw, act, bn, wpt
 
 
-def _bn_relu_bwd(dt, dy, raw, bn, train, pool, zero_bias=None):
-    """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv)."""
+def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta):
+    """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv); `bias`, `gamma`, `beta` are
+    the conv-bias / BN parameters (for their gradient destinations)."""
     B, C, H, W = raw.shape
     dev = raw.device
     s = _stream()
     nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
     partial = _f32(nblk * 2 * C, dev)
-    sums = _f32(2 * C, dev)
+    sums = grad_out_pair(beta, gamma)  # [sum g | sum g*xhat] = [dbeta | dgamma]
     L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
                     B, H, W, C, int(pool), s)
     L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), s)
@@ -287,9 +310,9 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, zero_bias=None):
     if train:
         # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
         # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8)
-        dbias = zero_bias if zero_bias is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        dbias = grad_out(bias).zero_()
     else:
-        dbias = _f32(C, dev)
+        dbias = grad_out(bias)
         npix = B * H * W
         part = _f32(L.colsum_blocks(npix, C, dt) * C, dev)
         L.colsum(dt, ptr(draw), npix, C, ptr(part), ptr(dbias), s)
@@ -309,6 +332,7 @@ class ConvBlockFn(torch.autograd.Function):
         raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad)
         ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
         ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
+        ctx.small = (b1, g1, be1, b2, g2, be2)  # leaf parameters: only their gradient destinations are needed
         return out
 
     @staticmethod
@@ -319,18 +343,18 @@ class ConvBlockFn(torch.autograd.Function):
         dev = raw2.device
         s = _stream()
         dout = as_nhwc(dout, raw2.dtype)
+        b1, g1, be1, b2, g2, be2 = ctx.small
         # ---- second conv layer
-        zb = torch.zeros(2 * C, dtype=torch.float32, device=dev) if train else None  # both conv-bias grads, one fill
-        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, zb[:C] if train else None)
-        dw2 = torch.empty_like(w2)
+        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2)
+        dw2 = grad_out(w2)
         _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
         if wp2t is None:
             wp2t = _pack_conv(w2, dt, True)
         da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
         igemm(dt, L.CONV3, draw2, C, None, 0, wp2t, None, da1, C, None, 0, None, B, H, W)
         # ---- first conv layer
-        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False, zb[C:] if train else None)
-        dw1 = torch.empty_like(w1)
+        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False, b1, g1, be1)
+        dw1 = grad_out(w1)
         _wgrad(dt, L.CONV3, x0, x1, draw1, dw1, B, H, W)
         dx0 = dx1 = None
         need0 = ctx.needs_input_grad[0]
@@ -358,7 +382,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         y = nhwc_empty(B, cout, 2 * H, 2 * W, x.dtype, x.device)
         igemm(dt, L.CONVT, x, cin, None, 0, wp, b, y, cout, None, 0, None, B, H, W)
         ctx.save_for_backward(x, w)
-        ctx.dt = dt
+        ctx.dt, ctx.bias = dt, b
         return y
 
     @staticmethod
@@ -370,11 +394,11 @@ class ConvT2x2Fn(torch.autograd.Function):
         dev = x.device
         s = _stream()
         dy = as_nhwc(dy, x.dtype)
-        dw = torch.empty_like(w)
+        dw = grad_out(w)
         _wgrad(dt, L.CONVT, dy, None, x, dw, B, H, W)
         npix = B * 4 * H * W
         part = _f32(L.colsum_blocks(npix, cout, dt) * cout, dev)
-        db = _f32(cout, dev)
+        db = grad_out(ctx.bias)
         L.colsum(dt, ptr(dy), npix, cout, ptr(part), ptr(db), s)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -417,7 +441,7 @@ class StemFn(torch.autograd.Function):
         y = nhwc_empty(B, cout, H, W, td, x.device)
         L.stem_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(y), B, cin, H, W, cout, _stream())
         ctx.save_for_backward(x)
-        ctx.dt, ctx.wshape = dt, w.shape
+        ctx.dt, ctx.wshape, ctx.params = dt, w.shape, (w, b)
         return y
 
     @staticmethod
@@ -430,8 +454,7 @@ class StemFn(torch.autograd.Function):
         dy = as_nhwc(dy, _tdtype("bf16" if ctx.dt == L.BF16 else "fp32"))
         nblk = L.stem_bwd_blocks(B, H, W)
         part = _f32(nblk * (cin + 1) * cout, x.device)
-        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
-        db = _f32(cout, x.device)
+        dw, db = grad_out(ctx.params[0]), grad_out(ctx.params[1])
         L.stem_bwd(ctx.dt, ptr(x), ptr(dy), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
         return None, dw, db, None
 
@@ -447,7 +470,7 @@ class HeadFn(torch.autograd.Function):
         logits = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
         L.head_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(logits), B, H, W, cin, cout, _stream())
         ctx.save_for_backward(x, w)
-        ctx.dt = dt
+        ctx.dt, ctx.bias = dt, b
         return logits
 
     @staticmethod
@@ -459,8 +482,7 @@ class HeadFn(torch.autograd.Function):
         nblk = L.head_bwd_blocks(B, H, W)
         part = _f32(nblk * cout * (cin + 1), x.device)
         dx = nhwc_empty(B, cin, H, W, x.dtype, x.device)
-        dw = torch.empty_like(w)
-        db = _f32(cout, x.device)
+        dw, db = grad_out(w), grad_out(ctx.bias)
         L.head_bwd(ctx.dt, ptr(x), ptr(dl), ptr(w), ptr(dx), ptr(part), ptr(dw), ptr(db), B, H, W, cin, cout, _stream())
         return dx, dw, db
 

@@ -70,6 +70,10 @@ def test_hook_path_matches_plain_backward_bitwise(pg):
             assert torch.equal(p.grad, r), f"iteration {it}: gradient differs from the plain step"
             assert any(p.grad.data_ptr() == v.data_ptr() for b in ddp.buckets for v in b.views)
     assert ddp.stats["zero_filled_slots"] == 0
+    # the HIP backward kernels wrote straight into the bucket slots: no hook-side copies were needed for them
+    assert ddp.stats["hook_copies"] == 0 and all(hasattr(p, "_hipseg_slot") for p in model.parameters())
+    ddp.remove_hooks()
+    assert not any(hasattr(p, "_hipseg_slot") for p in model.parameters())
     # BN buffers were re-pointed into the flat broadcast tensor and keep being updated by the kernels
     assert not torch.equal(model.enc1.block[0].conv[1].running_mean, rm_ref)
     lo = ddp._flat_buffers.data_ptr()
@@ -161,7 +165,9 @@ def test_unused_parameters_are_zero_filled_not_stale(pg):
             if ref[n] is None:
                 assert p.grad is None, n
                 bi, pi = ddp._where[p]
-                assert float(ddp.buckets[bi].views[pi].abs().max()) == 0.0, n
+                bucket = ddp.buckets[bi]
+                if any(q.grad is not None for q in bucket.params):  # (a wholly unused bucket is simply not reduced)
+                    assert float(bucket.views[pi].abs().max()) == 0.0, n
             else:
                 assert torch.equal(p.grad, ref[n]), n
         if overlap:

@@ -213,7 +213,7 @@ def test_bn_relu_pool_fwd_bwd(hs, prec, td, dt, pool, shape):
     assert int(nbt) == 1
     np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * xd.mean((0, 2, 3)).float().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * xd.var((0, 2, 3), unbiased=True)).float().numpy(), rtol=1e-4)
-    draw, dg, dbe, dbias = ops._bn_relu_bwd(dt, to_dev_nhwc(dy, td), raw, bn, True, pool)
+    draw, dg, dbe, dbias = ops._bn_relu_bwd(dt, to_dev_nhwc(dy, td), raw, bn, True, pool, torch.zeros(C, device="cuda"), gd, bd)
     torch.cuda.synchronize()
     check(draw, x.grad, td, scale=float(x.grad.abs().max()), what="bn bwd dx")
     rt = 2e-4 if td == torch.float32 else 2e-2
