@@ -52,6 +52,8 @@ def parse():
                          "captured inside it as side-stream branches overlapped with backward.  eager: Python "
                          "launches every kernel each step (all-reduce overlapped from autograd hooks).  splitgraph "
                          "(N > 1 only): hipGraph(fwd+bwd+pack) -> eager all-reduce (NOT overlapped) -> hipGraph(optimizer)")
+    ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
+                    help="hip: hipseg.optim.Adam (one HIP launch per step); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -207,8 +209,13 @@ def main():
     net = HipDDP(model, overlap=not split, force_collectives=force,
                  bucket_cap_mb=float(os.environ.get("HIPSEG_BUCKET_MB", "8"))) if ddp else model
     crit = HybridLoss()
-    opt = torch.optim.Adam([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=1e-4, fused=True,
-                           capturable=use_graph)
+    # the reference's optimizer (models/model_wrappers.py:40-41,124: Adam, lr 1e-3, weight_decay 1e-4)
+    trainable = [q for q in model.parameters() if q.requires_grad]
+    if args.optimizer == "hip":
+        from hipseg.optim import Adam as HipAdam
+        opt = HipAdam(trainable, lr=1e-3, weight_decay=1e-4)
+    else:
+        opt = torch.optim.Adam(trainable, lr=1e-3, weight_decay=1e-4, fused=True, capturable=use_graph)
     scaler = torch.amp.GradScaler("cuda")
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
@@ -339,6 +346,8 @@ def main():
                                f"BASELINE.json configs[{_config_index(args, world)}]",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "loop": loop_desc[loop_used],
+                   "optimizer": "hipseg.optim.Adam (HIP multi-tensor kernel)" if args.optimizer == "hip"
+                   else "torch.optim.Adam(fused=True)",
                    "weights": "random init (nn default)", "final_loss": round(final_loss, 5)},
         "ms_per_step_event_median": round(ev_ms[len(ev_ms) // 2], 4),
         "distributed": {"initialized": bool(ddp), "world_size": dist.get_world_size() if ddp else 1,

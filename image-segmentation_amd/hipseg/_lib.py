@@ -67,6 +67,9 @@ PROTOTYPES = {
     "hipseg_nchw_to_nhwc": (I, [I, P, P, I, I, I, I, P]),
     "hipseg_nhwc_to_nchw": (I, [I, P, P, I, I, I, I, P]),
     "hipseg_decode_records": (I, [P, P, P, P, P, I, I, I, P]),
+    "hipseg_adam_desc_size": (c_size_t, []),
+    "hipseg_adam_desc_fill": (I, [P, I, P, P, P, P, L]),
+    "hipseg_adam_step": (I, [P, I, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
     "hipseg_augment_workspace_elems": (c_size_t, [I]),
     "hipseg_augment": (I, [P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
 }
@@ -74,7 +77,7 @@ PROTOTYPES = {
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
-         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems"}
+         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size"}
 
 
 def _load():

@@ -19,18 +19,24 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+_ALIGN = 4  # slot starts are multiples of 4 floats = 16 bytes: vectorised optimiser / reduction kernels stay aligned
+
+
+def _aligned(n):
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work", "arrived")
+    __slots__ = ("flat", "params", "views", "offsets", "pending", "work", "arrived")
 
     def __init__(self, params, device):
-        n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
-        self.params = params
-        self.views = []
-        o = 0
+        self.offsets, o = [], 0
         for p in params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            self.offsets.append(o)
+            o += _aligned(p.numel())
+        self.flat = torch.zeros(o, dtype=torch.float32, device=device)  # (padding stays zero: reduced, never read)
+        self.params = params
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, params)]
         self.pending = len(params)
         self.arrived = [False] * len(params)
         self.work = None
@@ -113,11 +119,9 @@ class HipDDP(nn.Module):
         self._slotted = []
         if self.on_gpu and grad_in_bucket:
             for b in self.buckets:
-                o = 0
-                for p in b.params:
+                for p, o in zip(b.params, b.offsets):
                     p._hipseg_slot = (b.flat, o)
                     self._slotted.append(p)
-                    o += p.numel()
 
     def remove_hooks(self):
         """detach this reducer from the module's parameters (before wrapping the same module again)."""

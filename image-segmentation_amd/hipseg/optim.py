@@ -1,0 +1,107 @@
+"""Adam with the reference's hyper-parameter surface, as ONE HIP launch per parameter group.
+
+Drop-in for `torch.optim.Adam` where the reference's wrappers take `optimizer_class` / `optimizer_args`
+(models/model_wrappers.py:40-41,124: `optim.Adam`, `{'lr': 0.001, 'weight_decay': 1e-4}`), stepped through
+`GradScaler.step` (model_wrappers.py:176,979).  GradScaler hands `found_inf` / `grad_scale` to optimisers that declare
+`_step_supports_amp_scaling`; the kernel divides by the scale and skips the whole step on overflow, so no host sync
+and the step is hipGraph-capturable (the step counter lives on the device)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .ops import _require_gpu, _stream, ptr
+
+
+class Adam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True  # GradScaler.step passes .grad_scale / .found_inf instead of unscaling
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, maximize=False,
+                 foreach=None, capturable=True, differentiable=False, fused=None):
+        if amsgrad or maximize or differentiable:
+            raise NotImplementedError("hipseg.optim.Adam implements the reference's configuration "
+                                      "(amsgrad / maximize / differentiable off)")
+        if isinstance(lr, torch.Tensor):
+            lr = float(lr)
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= weight_decay or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError(f"invalid Adam hyper-parameters: lr={lr} betas={betas} eps={eps} weight_decay={weight_decay}")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._hip = {}  # group index -> per-group device state
+
+    # ------------------------------------------------------------------ per-group state
+    def _group_state(self, gi, group):
+        st = self._hip.get(gi)
+        params = [p for p in group["params"]]
+        if st is not None and st["params"] is not None and len(st["params"]) == len(params) and \
+                all(a is b for a, b in zip(st["params"], params)):
+            return st
+        for p in params:
+            _require_gpu(p)
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("hipseg.optim.Adam updates contiguous fp32 parameters")
+        dev = params[0].device
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)
+        # moments live in two flat allocations (16-byte aligned slices); exposed per parameter through self.state
+        flat_m, flat_v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        o = 0
+        for p in params:
+            s = self.state[p]
+            m, v = flat_m[o:o + p.numel()].view_as(p), flat_v[o:o + p.numel()].view_as(p)
+            if "exp_avg" in s:  # (state loaded from a checkpoint)
+                m.copy_(s["exp_avg"])
+                v.copy_(s["exp_avg_sq"])
+            s["exp_avg"], s["exp_avg_sq"] = m, v
+            o += (p.numel() + 3) // 4 * 4
+        st = {"params": params, "flat": (flat_m, flat_v), "counter": torch.zeros(2, dtype=torch.int32, device=dev),
+              "tables": {}}
+        self._hip[gi] = st
+        return st
+
+    def _table(self, st, active):
+        """host descriptor table for the parameters that have a gradient; cached per pointer set (the caching allocator
+        hands back the same gradient addresses step after step).  Read by hipseg_adam_step during the call only."""
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in active)
+        t = st["tables"].get(key)
+        if t is not None:
+            return t
+        if len(st["tables"]) > 16:
+            st["tables"].clear()
+        host = ctypes.create_string_buffer(len(active) * L.adam_desc_size())
+        for i, p in enumerate(active):
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+                raise TypeError("hipseg.optim.Adam needs contiguous fp32 gradients on the parameter's device")
+            s = self.state[p]
+            L.adam_desc_fill(ctypes.addressof(host), i, ptr(p), ptr(g), ptr(s["exp_avg"]), ptr(s["exp_avg_sq"]), p.numel())
+        st["tables"][key] = host
+        return host
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        found_inf = getattr(self, "found_inf", None)
+        grad_scale = getattr(self, "grad_scale", None)
+        for gi, group in enumerate(self.param_groups):
+            if not group["params"]:
+                continue
+            st = self._group_state(gi, group)
+            active = [p for p in st["params"] if p.grad is not None]
+            if not active:
+                continue
+            host = self._table(st, active)
+            b1, b2 = group["betas"]
+            L.adam_step(ctypes.addressof(host), len(active), ptr(st["counter"]),
+                        ptr(found_inf.float() if found_inf is not None else None),
+                        ptr(grad_scale.float() if grad_scale is not None else None),
+                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                        _stream())
+        return loss
+
+    def step_count(self, group=0):
+        """number of applied (non-skipped) steps of a group (host sync)."""
+        st = self._hip.get(group)
+        return 0 if st is None else int(st["counter"][0])

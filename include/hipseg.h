@@ -229,6 +229,19 @@ int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H,
 int hipseg_decode_records(const uint8_t* images, const uint8_t* masks, float* out_images, int64_t* out_masks,
                           int* cat_flags, int n, int H, int W, hipseg_stream_t stream);
 
+/* ---- optimiser step ----------------------------------------------------------------------------------
+ * replaces: torch.optim.Adam.step as driven by GradScaler.step (models/model_wrappers.py:124,176,979): the whole
+ * parameter group in ceil(ntensors / 64) launches.  host_descs: HOST table of hipseg_adam_desc_size()-byte entries
+ * {param, grad, exp_avg, exp_avg_sq (device fp32 pointers), numel} filled by hipseg_adam_desc_fill; it is read during
+ * the call only (descriptors travel by value in the kernel arguments).
+ * state: device int[2] {step count, internal arrival counter (0)}.  found_inf / grad_scale: device floats or NULL
+ * (GradScaler contract: found_inf != 0 skips the step entirely; gradients are divided by grad_scale). */
+size_t hipseg_adam_desc_size(void);
+int hipseg_adam_desc_fill(void* host_descs, int index, float* p, const float* g, float* m, float* v, long n);
+int hipseg_adam_step(const void* host_descs, int ntensors, int* state, const float* found_inf,
+                     const float* grad_scale, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, hipseg_stream_t stream);
+
 /* ---- on-device training augmentation (the per-step caller in front of the path) -------------------
  * replaces: DataAugmentor.forward / DataAugmentorPrompt.forward, models/processing_blocks.py:344-384,386-451 (kornia
  * RandomHorizontalFlip + RandomRotation(90, nearest) on image||mask[||prompt], ColorJitter + RandomGaussianBlur(5x5) on

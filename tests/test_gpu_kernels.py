@@ -348,3 +348,75 @@ def test_pack_batch_matches_per_layer_pack(hs, prec, td, dt):
     with torch.no_grad():
         net[0].weight.add_(1.0)
     assert ops._cached_pack(net[0].weight, dt) is None
+
+
+def test_hip_adam_matches_torch_adam():
+    """hipseg.optim.Adam == torch.optim.Adam (the reference's optimizer_class, models/model_wrappers.py:40,124) over
+    several steps: weight decay, odd sizes (vector tails, unaligned views), a parameter without gradient, the
+    GradScaler contract (grad_scale division, found_inf skips the step and does not count it) and hipGraph replay."""
+    from hipseg.optim import Adam
+
+    torch.manual_seed(0)
+    shapes = [(3,), (64, 32, 3, 3), (513,), (4099,), (1, 1), (128, 64, 2, 2), (9001,)]
+    ref_p = [torch.randn(s, dtype=torch.float32).requires_grad_(True) for s in shapes]
+    flat = torch.zeros(sum(p.numel() for p in ref_p) + 1, device="cuda")
+    dev_p = [p.detach().clone().cuda().requires_grad_(True) for p in ref_p]
+    ref_p.append(torch.randn(7).requires_grad_(True))          # never receives a gradient
+    dev_p.append(ref_p[-1].detach().clone().cuda().requires_grad_(True))
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    ref = torch.optim.Adam(ref_p, **kw)
+    opt = Adam(dev_p, **kw)
+    scale = torch.tensor([1024.0], device="cuda")
+    applied = 0
+    for it in range(7):
+        grads = [torch.randn(s) * (10.0 ** (it % 3 - 1)) for s in shapes]
+        overflow = it == 3
+        o = 1  # gradients live at odd offsets of one flat buffer on some steps (unaligned -> scalar path)
+        for p, rp, g in zip(dev_p, ref_p, grads):
+            if it % 2:
+                view = flat[o:o + g.numel()].view(g.shape)
+                view.copy_(g * 1024.0)
+                p.grad = view
+                o += g.numel()
+            else:
+                p.grad = (g * 1024.0).cuda()
+            rp.grad = g.clone()
+        opt.grad_scale = scale
+        opt.found_inf = torch.tensor([1.0 if overflow else 0.0], device="cuda")
+        opt.step()
+        if not overflow:
+            ref.step()
+            applied += 1
+        for p, rp in zip(dev_p, ref_p):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=2e-5, atol=2e-6)
+    assert opt.step_count() == applied == 6
+    assert torch.equal(dev_p[-1].cpu(), ref_p[-1])  # no gradient -> untouched (no weight decay either), as torch
+    np.testing.assert_allclose(opt.state[dev_p[1]]["exp_avg_sq"].cpu().numpy(), ref.state[ref_p[1]]["exp_avg_sq"].numpy(),
+                               rtol=1e-4, atol=1e-9)
+    del opt.grad_scale, opt.found_inf
+    # hipGraph: static gradient buffers, the device-side step counter advances on every replay
+    for p in dev_p[:-1]:
+        p.grad = torch.zeros_like(p)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        opt.step()  # warm-up: builds the table for these gradient addresses
+        ref_grads = [torch.zeros(sh) for sh in shapes]
+        for rp, g in zip(ref_p, ref_grads):
+            rp.grad = g
+        ref.step()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            opt.step()
+        for it in range(3):
+            for p, rp in zip(dev_p[:-1], ref_p):
+                g = torch.randn(p.shape)
+                p.grad.copy_(g)
+                rp.grad = g
+            graph.replay()
+            ref.step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert opt.step_count() == applied + 1 + 3
+    for p, rp in zip(dev_p, ref_p):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=5e-5, atol=5e-6)
