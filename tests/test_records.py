@@ -88,3 +88,55 @@ def test_decode_records_gpu_bit_exact():
     assert np.array_equal(gm[0].cpu().numpy(), wm0) and np.array_equal(gm[1].cpu().numpy(), wm1)
     with pytest.raises(Exception):
         D.decode_records(torch.zeros(1, 3, 3, 3, dtype=torch.uint8).cuda(), torch.zeros(1, 3, 3, dtype=torch.uint8).cuda())
+
+
+def test_pt_dataset_cache_format(tmp_path, rec_golden):
+    """`.pt` cache of customDatasets/datasets.py:64-83: a list of (image float32 CHW, mask int64 HW) tuples written by
+    torch.save and read with weights_only=True -- files written the reference's way load here, files written here
+    load the reference's way, entry for entry (entries = the pinned oracle's decode of the synthetic records)."""
+    import hipseg.data as D
+
+    images, masks = records.make_records()
+    # the reference's loop: dataset_cache.append(self._deserialize_datapoint(datapoint)); torch.save(dataset_cache, f)
+    ref_cache = []
+    for i in range(images.shape[0]):
+        img, msk = records.decode_record(images[i].tobytes(), masks[i].tobytes())
+        assert np.array_equal(msk, rec_golden[f"mask_out_{i}"].astype(np.int64))  # == the reference's own output
+        ref_cache.append((torch.from_numpy(img), torch.tensor(msk)))
+    ref_file = tmp_path / "train_dataset.pt"
+    assert D.cache_path(str(tmp_path), "train") == str(ref_file)
+    torch.save(ref_cache, ref_file)
+    got = D.load_dataset_cache(ref_file)
+    assert len(got) == len(ref_cache)
+    for (gi, gm), (ri, rm) in zip(got, ref_cache):
+        assert gi.dtype == torch.float32 and gm.dtype == torch.int64 and torch.equal(gi, ri) and torch.equal(gm, rm)
+    si, sm = D.load_dataset_cache(ref_file, device="cpu")
+    assert si.shape == (6, 3, 256, 256) and sm.shape == (6, 256, 256) and torch.equal(si[2], ref_cache[2][0])
+    # and the other way round: our writer -> the reference's reader (torch.load(cache_file, weights_only=True))
+    ours = tmp_path / "validation_dataset.pt"
+    D.save_dataset_cache(ours, got)
+    back = torch.load(ours, weights_only=True)
+    assert isinstance(back, list) and all(isinstance(e, tuple) and len(e) == 2 for e in back)
+    for (bi, bm), (ri, rm) in zip(back, ref_cache):
+        assert torch.equal(bi, ri) and torch.equal(bm, rm)
+    with pytest.raises(TypeError):
+        D.save_dataset_cache(tmp_path / "bad.pt", [(torch.zeros(3, 4, 4), torch.zeros(4, 4))])
+    torch.save({"a": torch.zeros(1)}, tmp_path / "notcache.pt")
+    with pytest.raises(ValueError):
+        D.load_dataset_cache(tmp_path / "notcache.pt")
+
+
+@pytest.mark.gpu
+def test_build_dataset_cache_on_gpu():
+    """records -> cache entries through the HIP decode kernel == the oracle's per-record decode, bit for bit."""
+    import hipseg.data as D
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    images, masks = records.make_records()
+    cache = D.build_dataset_cache(torch.from_numpy(images), torch.from_numpy(masks), chunk=4)
+    assert len(cache) == images.shape[0]
+    for i, (img, msk) in enumerate(cache):
+        ri, rm = records.decode_record(images[i].tobytes(), masks[i].tobytes())
+        assert img.dtype == torch.float32 and msk.dtype == torch.int64
+        assert np.array_equal(img.numpy(), ri) and np.array_equal(msk.numpy(), rm)
