@@ -1,6 +1,8 @@
 // BatchNorm2d (+ReLU, +MaxPool2d(2,2)) forward/backward pieces and per-channel reductions, NHWC.
 // All kernels are HBM-bound: 16-byte vector accesses (8 bf16 / 4 f32 channels per lane), fp32
 // math, per-channel sums reduced lane -> LDS -> per-block partial -> fixed-order finalize.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -24,6 +26,23 @@ __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e) t[e] = (T)v[e];
         *reinterpret_cast<typename VecOf<T>::type*>(p) = t;
+    }
+}
+
+// V consecutive per-channel fp32 constants as 16-byte loads (V = 8 / 4: channel vectors are 32- / 16-byte aligned),
+// all issued before any use -- scalar loads interleaved with selects serialise into one memory round trip per element
+template <int V>
+__device__ __forceinline__ void ldc(const float* __restrict__ p, float (&v)[V]) {
+    if constexpr (V % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = p[e];
     }
 }
 
@@ -93,48 +112,75 @@ __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, con
 }
 
 // ------------------------------------------------------------------ y = [maxpool2x2](relu(x*scale + shift))
+#ifndef BN_APPLY_UNR
+#define BN_APPLY_UNR 1
+#endif
+#ifndef BN_APPLY_MAXBLK
+#define BN_APPLY_MAXBLK 4096
+#endif
+// Grid-stride over (output pixel, channel vector) items; BN_APPLY_UNR independent items per lane and iteration, all
+// their loads issued before the first use (a single 16-byte load per lane leaves too few bytes in flight per CU to
+// cover the HBM latency at full bandwidth).
 template <typename T, int V, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ y,
                                                              int B, int H, int W, int C) {
+    constexpr int UNR = POOL ? 1 : BN_APPLY_UNR;
     const int CG = C / V;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
     const long total = (long)B * Ho * Wo * CG;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const long op = i / CG;
-        float sc[V], sh[V], o[V];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < total; i0 += stride * UNR) {
+        float v[UNR][POOL ? 4 : 1][V];
+        long op[UNR];
+        int cg[UNR];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            sc[e] = scale[cg * V + e];
-            sh[e] = shift[cg * V + e];
-        }
-        if (!POOL) {
-            float v[V];
-            ldv<T, V>(x + op * C + cg * V, v);
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i < total) {
+                cg[u] = (int)(i % CG);
+                op[u] = i / CG;
+                if (!POOL) {
+                    ldv<T, V>(x + op[u] * C + cg[u] * V, v[u][0]);
+                } else {
+                    const int xo = (int)(op[u] % Wo);
+                    const int yo = (int)((op[u] / Wo) % Ho);
+                    const long n = op[u] / ((long)Wo * Ho);
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
-        } else {
-            const int xo = (int)(op % Wo);
-            const int yo = (int)((op / Wo) % Ho);
-            const long n = op / ((long)Wo * Ho);
-#pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = 0.f;  // relu output >= 0
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long ip = (n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
-                float v[V];
-                ldv<T, V>(x + ip * C + cg * V, v);
-#pragma unroll
-                for (int e = 0; e < V; ++e) o[e] = fmaxf(o[e], v[e] * sc[e] + sh[e]);
+                    for (int k = 0; k < 4; ++k) {
+                        const long ip = (n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+                        ldv<T, V>(x + ip * C + cg[u] * V, v[u][k]);
+                    }
+                }
             }
         }
-        stv<T, V>(y + op * C + cg * V, o);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i < total) {
+                float sc[V], sh[V], o[V];
+                ldc<V>(scale + cg[u] * V, sc);
+                ldc<V>(shift + cg[u] * V, sh);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = 0.f;  // relu output >= 0
+#pragma unroll
+                for (int k = 0; k < (POOL ? 4 : 1); ++k)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = fmaxf(o[e], v[u][k][e] * sc[e] + sh[e]);
+                stv<T, V>(y + op[u] * C + cg[u] * V, o);
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------ block geometry of the channel reductions
 // thread -> (channel group cg = tid % CG, pixel lane pl = tid / CG); PL = 256 / CG pixel lanes.
+#ifndef BN_MAXBLK
+#define BN_MAXBLK 1024
+#endif
+#ifndef BN_UNR
+#define BN_UNR 2
+#endif
 struct RedGeo {
     int CG, PL, nblk;
     long ppb;  // pixels per block
@@ -144,7 +190,7 @@ inline RedGeo red_geo(long npix, int C, int V) {
     g.CG = C / V;
     g.PL = 256 / g.CG;
     long nb = (npix + (long)g.PL * 8 - 1) / ((long)g.PL * 8);
-    if (nb > 1024) nb = 1024;
+    if (nb > BN_MAXBLK) nb = BN_MAXBLK;
     if (nb < 1) nb = 1;
     g.nblk = (int)nb;
     g.ppb = (npix + nb - 1) / nb;
@@ -229,17 +275,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int e = 0; e < V; ++e) s1[e] = s2[e] = 0.f;
     if (pl < PL) {
         float mn[V], is[V], sc[V], sh[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            mn[e] = mean[cg * V + e];
-            is[e] = invstd[cg * V + e];
-            sc[e] = scale[cg * V + e];
-            sh[e] = shift[cg * V + e];
-        }
+        ldc<V>(mean + cg * V, mn);
+        ldc<V>(invstd + cg * V, is);
+        ldc<V>(scale + cg * V, sc);
+        ldc<V>(shift + cg * V, sh);
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix_out) end = npix_out;
-        constexpr int UNR = POOL ? 2 : 4;  // pixels in flight per lane
+        constexpr int UNR = POOL ? 2 : BN_UNR;  // pixels in flight per lane
         for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
             PixelCtx<T, V, POOL> ctx[UNR];
 #pragma unroll
@@ -298,19 +341,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int e = 0; e < V; ++e) sb[e] = 0.f;
     if (pl < PL) {
         float mn[V], is[V], sc[V], sh[V], k1[V], k2[V];
+        ldc<V>(mean + cg * V, mn);
+        ldc<V>(invstd + cg * V, is);
+        ldc<V>(scale + cg * V, sc);
+        ldc<V>(shift + cg * V, sh);
+        ldc<V>((eval ? mean : sums) + cg * V, k1);      // dbeta / N   (eval: any valid address, value unused)
+        ldc<V>((eval ? mean : sums + C) + cg * V, k2);  // dgamma / N
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            mn[e] = mean[cg * V + e];
-            is[e] = invstd[cg * V + e];
-            sc[e] = scale[cg * V + e];
-            sh[e] = shift[cg * V + e];
-            k1[e] = eval ? 0.f : sums[cg * V + e] * inv_count;      // dbeta / N
-            k2[e] = eval ? 0.f : sums[C + cg * V + e] * inv_count;  // dgamma / N
+            k1[e] = eval ? 0.f : k1[e] * inv_count;
+            k2[e] = eval ? 0.f : k2[e] * inv_count;
         }
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix_out) end = npix_out;
-        constexpr int UNR = POOL ? 2 : 4;  // pixels in flight per lane
+        constexpr int UNR = POOL ? 2 : BN_UNR;  // pixels in flight per lane
         for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
             PixelCtx<T, V, POOL> ctx[UNR];
 #pragma unroll
@@ -395,7 +440,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 // out[r][c] = sum_blk partial[blk][r][c]; block = 16 columns x 16 block-slices, fixed order, one launch.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int RC,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, float* __restrict__ zero_out,
+                                                               int nzero) {
+    if (zero_out)  // rides along: an exactly-zero gradient vector (conv bias in front of a train-mode BatchNorm)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nzero; i += gridDim.x * 256) zero_out[i] = 0.f;
     __shared__ float sm[16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -482,7 +530,8 @@ extern "C" int hipseg_bn_relu_apply(int dtype, const void* x, const float* scale
     const int V = vec_for(C, dtype);
     const long total = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / V);
     long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
+    if (!pool) g = (g + BN_APPLY_UNR - 1) / BN_APPLY_UNR;
+    if (g > BN_APPLY_MAXBLK) g = BN_APPLY_MAXBLK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
         if (pool)
@@ -558,12 +607,12 @@ extern "C" int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, con
     return HIPSEG_OK;
 }
 
-extern "C" int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out,
+extern "C" int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out, float* zero_out,
                                       hipseg_stream_t stream) {
     HS_REQUIRE(partial && out && nblk > 0 && rows > 0 && C > 0, "colsum_finalize: bad arguments");
     const int RC = rows * C;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       partial, nblk, RC, out);
+                       partial, nblk, RC, out, zero_out, C);
     HS_LAUNCH_CHECK("colsum_finalize");
     return HIPSEG_OK;
 }
@@ -583,5 +632,5 @@ extern "C" int hipseg_colsum(int dtype, const void* x, long npix, int C, float* 
                            g.CG, g.PL, g.ppb);
     });
     HS_LAUNCH_CHECK("colsum");
-    return hipseg_colsum_finalize(partial, g.nblk, 1, C, out, stream);
+    return hipseg_colsum_finalize(partial, g.nblk, 1, C, out, nullptr, stream);
 }

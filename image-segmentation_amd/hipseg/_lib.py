@@ -47,7 +47,7 @@ PROTOTYPES = {
     "hipseg_bn_bwd_blocks": (I, [I, I, I, I, I, I]),
     "hipseg_bn_bwd_reduce": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_bn_bwd_apply": (I, [I, P, P, P, P, P, P, P, c_double, I, P, P, I, I, I, I, I, P]),
-    "hipseg_colsum_finalize": (I, [P, I, I, I, P, P]),
+    "hipseg_colsum_finalize": (I, [P, I, I, I, P, P, P]),
     "hipseg_colsum_blocks": (I, [L, I, I]),
     "hipseg_colsum": (I, [I, P, L, I, P, P, P]),
     "hipseg_stem_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),

@@ -303,16 +303,14 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta):
     sums = grad_out_pair(beta, gamma)  # [sum g | sum g*xhat] = [dbeta | dgamma]
     L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
                     B, H, W, C, int(pool), s)
-    L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), s)
+    # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
+    # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8).  The finalize launch writes it.
+    dbias = grad_out(bias)
+    L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), ptr(dbias) if train else 0, s)
     draw = nhwc_empty(B, C, H, W, raw.dtype, dev)
     L.bn_bwd_apply(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
                    float(B * H * W), 0 if train else 1, ptr(draw), 0, B, H, W, C, int(pool), s)
-    if train:
-        # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
-        # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8)
-        dbias = grad_out(bias).zero_()
-    else:
-        dbias = grad_out(bias)
+    if not train:
         npix = B * H * W
         part = _f32(L.colsum_blocks(npix, C, dt) * C, dev)
         L.colsum(dt, ptr(draw), npix, C, ptr(part), ptr(dbias), s)

@@ -155,9 +155,10 @@ int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* m
                         const float* sums, double count, int eval, void* dx, float* dbias, int B,
                         int H, int W, int C, int pool, hipseg_stream_t stream);
 
-/* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic).  The partial
- * workspace is clobbered (in-place tree).  bn_finalize likewise clobbers its `stats` workspace. */
-int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out,
+/* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic).  zero_out != NULL: the same
+ * launch also writes zero_out[0..C) = 0 (the conv-bias gradient in front of a train-mode BatchNorm is exactly 0).
+ * bn_finalize clobbers its `stats` workspace. */
+int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C, float* out, float* zero_out,
                            hipseg_stream_t stream);
 /* per-channel sum over pixels of an NHWC tensor: out[c] = sum_p x[p][c] (bias gradients). */
 int hipseg_colsum_blocks(long npix, int C, int dtype);
