@@ -704,6 +704,165 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One-tap GEMM kernel for the ConvTranspose2d(k2, s2) pair: forward (MODE CONVT: M = input pixels, K = Cin,
+// N = 4*Cout, pixel-shuffle store) and data gradient (MODE CONV2S2 seen as ONE tap over K = 4 taps x Cout gathered
+// channels, N = Cin).  The generic ring kernel stages 16 channels per barrier as an [octet][pixel][8] GATHER (64 cache
+// lines touched per 1-KiB LDS-DMA piece) -- fine when 9 taps reuse the chunk, but with one tap that is 4 MFMAs per wave
+// per barrier against ~8 KiB of gather-rate DMA: 0.04-0.10 of the MFMA peak (rocprof r01).  Without a halo the
+// activation tile can instead keep the global pixel-major order: a stage is 256 pixels x 64 channels, every 1-KiB piece
+// = 8 pixels x 128 B = 8 whole cache lines, 16 MFMAs per wave per barrier.  The 16-byte slots of a pixel row are
+// XOR-swizzled (on the DMA's SOURCE side, LDS destinations stay linear) so the 16 pixel rows a ds_read_b128 half-wave
+// touches fall on 16 different (bank half, slot) pairs: conflict-free fragment reads out of 128-byte rows.
+// Weights: [k-octet][n][8] packed operand, chunk read into VGPRs one stage ahead and written with ds_write_b128, as in
+// the ring kernels.  Needs C0 % 64 == 0 and N % 128 == 0 (every ConvT of the U-Nets but dec4's data gradient).
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm1_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef bf16 T;
+    constexpr int BN = 128, NW = 8, THT = 16, NBUF = 3, DIST = NBUF - 1;
+    constexpr int KCH = 64, KS = KCH / 16;  // channels per stage, k16 MFMA steps per stage
+    constexpr int A_BYTES = 256 * KCH * 2, B_BYTES = (KCH / 8) * BN * 16, BUF = A_BYTES + B_BYTES;
+    constexpr int NAW = A_BYTES / 1024 / NW, NBW = B_BYTES / 1024 / NW;  // 1-KiB pieces per wave and stage: 4, 2
+    constexpr int EMODE = MODE == HIPSEG_CONVT ? HIPSEG_CONVT : HIPSEG_CONV1;  // epilogue: pixel shuffle / plain NHWC
+    constexpr int WN = WG<BN, NW, THT>::WN, MT = WG<BN, NW, THT>::MT, NTL = WG<BN, NW, THT>::NTL;
+    static_assert(NAW == 4 && NBW == 2 && MT == 2 && NTL == 2, "geometry");
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_block(blockIdx.x, p.xcd);
+    const int ntile = bid % p.ntn, mtile = bid / p.ntn;
+    const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y, img = mtile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * THT, x0 = tx * TW, n0 = ntile * BN;
+    const int Ktot = MODE == HIPSEG_CONVT ? p.C0 : 4 * p.C0;
+
+    constexpr unsigned OOB_LANE = 0x80000000u;
+    const unsigned in_bytes = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C0 * sizeof(T));
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in0), 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.wp), 0, (int)((size_t)Ktot * p.Np * sizeof(T)), 0x00020000);
+
+    auto swz = [](int pix) { return (pix & 7) ^ ((pix >> 3) & 1); };
+    // A pieces of this wave: piece s = j * NW + wave holds tile pixels 8s .. 8s+7 (half a tile row); lane -> (pixel, slot)
+    unsigned avo[NAW];
+#pragma unroll
+    for (int j = 0; j < NAW; ++j) {
+        const int sidx = j * NW + wave;
+        const int pix = sidx * 8 + (lane >> 3);
+        const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+        const bool ok = gy < p.H && gx < p.W;
+        const long ipix = MODE == HIPSEG_CONVT ? ((long)img * p.Hi + gy) * p.Wi + gx : ((long)img * p.Hi + 2 * gy) * p.Wi + 2 * gx;
+        avo[j] = ok ? (unsigned)(ipix * p.C0 * (long)sizeof(T)) + (unsigned)(((lane & 7) ^ swz(pix)) * 16) : OOB_LANE;
+    }
+    // B pieces: piece s covers k-octet s/2, columns (s&1)*64 + lane of the 128-wide tile
+    unsigned bvo[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int sidx = j * NW + wave;
+        bvo[j] = (unsigned)((((size_t)(sidx >> 1) * p.Np) + n0 + (sidx & 1) * 64 + lane) * 16);
+    }
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i bst[NBW];
+    auto loadB = [&](int c) {
+        const unsigned so = (unsigned)(c * (KCH / 8)) * (unsigned)p.Np * 16u;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bst[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_w, bvo[j], so, 0));
+    };
+    auto writeB = [&](int buf) {
+        unsigned char* base = smem + buf * BUF + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) *reinterpret_cast<v4i*>(base + (j * NW + wave) * 1024 + lane * 16) = bst[j];
+    };
+    auto issue_piece = [&](int buf, int c, int j) {
+        const int k0 = c * KCH;
+        unsigned so;
+        if (MODE == HIPSEG_CONVT) {
+            so = (unsigned)k0 * (unsigned)sizeof(T);
+        } else {  // chunk = 64 channels of tap (a, b): input pixel (2y + a, 2x + b)
+            const int tap = k0 / p.C0, co0 = k0 - tap * p.C0;
+            so = (unsigned)((((tap >> 1) * p.Wi + (tap & 1)) * p.C0 + co0) * (int)sizeof(T));
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void*)(smem + buf * BUF + (j * NW + wave) * 1024), 16, avo[j], so, 0,
+                                                 0);
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int apix[MT], asw[MT], ncol[NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        apix[i] = 32 * (wm * MT + i) + r;  // tile pixel of MFMA row r of sub-tile i (two 16-pixel tile rows)
+        asw[i] = swz(apix[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
+
+    const int nchunks = Ktot / KCH;
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nchunks) {
+#pragma unroll
+            for (int q = 0; q < NAW; ++q) issue_piece(d, d, q);
+        }
+    loadB(0);
+    writeB(0);
+    int cur = 0;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        if (kc + DIST - 1 < nchunks)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NAW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kc + DIST < nchunks, moreB = kc + 1 < nchunks;
+        if (moreB) loadB(kc + 1);
+        const int nbuf = (cur + DIST) % NBUF;
+        const unsigned char* sA = smem + cur * BUF;
+        const unsigned char* sB = sA + A_BYTES;
+        cur = (cur + 1) % NBUF;
+        bf16x8 bf[2][NTL], af[2][MT];
+        auto fetch = [&](int slot, int t) {
+            const int oct = 2 * t + h;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)oct * BN + ncol[j]) * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + (size_t)apix[i] * (KCH * 2) + ((oct ^ asw[i]) * 16));
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][0], bf[t & 1][j], acc[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < KS) fetch((t + 1) & 1, t + 1);
+            if (more) issue_piece(nbuf, kc + DIST, t);  // NAW == KS: one piece per k16 step
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][1], bf[t & 1][j], acc[1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (moreB) writeB(cur);
+    }
+    static_assert(NAW == KS, "one activation piece per k16 step");
+    conv_epilogue<bf16, EMODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+#else
+    (void)p;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 ring kernel with ACTIVATION SUPER-CHUNKS (128-wide tile, >= 128 input channels).  The plain ring kernel gathers
 // 16 B (one k-octet) per halo pixel per DMA lane and comes back for the neighbouring octets of the same cache line
 // one, two and three 16-channel chunks later -- long after the line left the 32-KiB L1 -- so every activation line is
@@ -1496,6 +1655,24 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     return HIPSEG_OK;
 }
 
+template <int MODE>
+int launch_gemm1(const ConvArgs& a0, hipStream_t s) {
+    constexpr size_t lds = 3 * (size_t)(256 * 64 * 2 + 8 * 128 * 16);  // ring (144 KiB) > epilogue scratch (64 KiB)
+    ConvArgs a = a0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
+    a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
+    hipLaunchKernelGGL((gemm1_kernel<MODE>), dim3((unsigned)grid), dim3(512), lds, s, a);
+    HS_LAUNCH_CHECK("conv_gemm1");
+    return HIPSEG_OK;
+}
+
 template <int THT, int SO>
 int launch_ring64(const ConvArgs& a0, hipStream_t s) {
     typedef A64Geo<THT, SO> G;
@@ -1669,6 +1846,13 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
         if (a.vec_ok && !no_dma && buf_ok) {
+            // ConvTranspose2d forward / data gradient as a one-tap GEMM on pixel-major 64-channel stages
+            static const bool no_g1 = getenv("HIPSEG_NO_GEMM1") != nullptr;  // A/B switch
+            // (K >= 256: with one or two 64-channel stages there is nothing to pipeline and the 144-KiB ring allows one
+            // workgroup per CU -- measured 32 vs 28 us on dec4.up, 19 vs 18 on dec3.up)
+            if (!no_g1 && !dbg && (mode == HIPSEG_CONVT || mode == HIPSEG_CONV2S2) && C1 == 0 && N1 == 0 && C0 % 64 == 0 &&
+                a.N % 128 == 0 && a.Kp == C0 && N0 % 8 == 0 && (mode == HIPSEG_CONVT ? C0 : 4 * C0) >= 256)
+                return mode == HIPSEG_CONVT ? launch_gemm1<HIPSEG_CONVT>(a, s) : launch_gemm1<HIPSEG_CONV2S2>(a, s);
             // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)
             static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
             const long tall_wgs = (long)a.B * a.tiles_x * cdiv(H, 32) * a.ntn;

@@ -40,31 +40,42 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ y, int B, int Cin,
                                                         long HW, int Cout) {
+    // index arithmetic in 32 bits (launch condition: B*HW*CG < 2^31): a 64-bit divide costs ~100 VALU instructions,
+    // and three of them per 16-byte store made this kernel ALU-bound at a third of the HBM rate
     const int CG = Cout / V;
-    const long total = (long)B * HW * CG;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const unsigned hw_n = (unsigned)HW;
+    const unsigned total = (unsigned)B * hw_n * CG;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (Cin <= MAXCIN && stride % CG == 0) {
         // the channel group of a lane never changes along its grid-stride walk: keep its weights in registers
+        // (loads are unconditional -- clamped index, then select -- so they all issue before the first wait)
         const int cg = (int)(i0 % CG);
         float wr[MAXCIN][V], br[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             br[e] = b[cg * V + e];
 #pragma unroll
-            for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? w[(cg * V + e) * Cin + ci] : 0.f;
+            for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = w[(cg * V + e) * Cin + (ci < Cin ? ci : Cin - 1)];
         }
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? wr[ci][e] : 0.f;
         constexpr int UNR = 4;  // pixels in flight per lane (the loop is latency-bound otherwise: 3 loads -> 1 store)
-        for (long i = i0; i < total; i += stride * UNR) {
+        for (unsigned i = i0; i < total; i += stride * UNR) {
             float xv[UNR][MAXCIN];
             long pp[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const long iu = i + u * stride;
-                pp[u] = iu < total ? iu / CG : -1;
-                const long n = pp[u] / HW, hw = pp[u] % HW;
+                const unsigned iu = i + u * stride;
+                const bool ok = iu < total && iu >= i;  // (>= i: no wrap-around)
+                const unsigned pu = ok ? iu / CG : 0u;
+                pp[u] = ok ? (long)pu : -1;
+                const unsigned n = pu / hw_n, hw = pu - n * hw_n;
 #pragma unroll
-                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = (pp[u] >= 0 && ci < Cin) ? x[(n * Cin + ci) * HW + hw] : 0.f;
+                for (int ci = 0; ci < MAXCIN; ++ci)
+                    xv[u][ci] = (ok && ci < Cin) ? x[((size_t)n * Cin + ci) * hw_n + hw] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -83,19 +94,19 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         }
         return;
     }
-    for (long i = i0; i < total; i += stride) {
+    for (unsigned i = i0; i < total; i += stride) {
         const int cg = (int)(i % CG);
-        const long p = i / CG;  // n*HW + pixel
-        const long n = p / HW, hw = p % HW;
+        const unsigned p = i / CG;  // n*HW + pixel
+        const unsigned n = p / hw_n, hw = p - n * hw_n;
         float o[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = b[cg * V + e];
         for (int ci = 0; ci < Cin; ++ci) {
-            const float xv = x[(n * Cin + ci) * HW + hw];
+            const float xv = x[((size_t)n * Cin + ci) * hw_n + hw];
 #pragma unroll
             for (int e = 0; e < V; ++e) o[e] = fmaf(w[(cg * V + e) * Cin + ci], xv, o[e]);
         }
-        stv<T, V>(y + p * Cout + cg * V, o);
+        stv<T, V>(y + (size_t)p * Cout + cg * V, o);
     }
 }
 
@@ -124,10 +135,11 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
             for (int u = 0; u < UNR; ++u) {
                 const long p = p0 + (long)u * PL;
                 if (p < end) {
-                    const long n = p / HW, hw = p % HW;
+                    const unsigned pu = (unsigned)p, hw_n = (unsigned)HW;  // 32-bit divide (launch condition)
+                    const unsigned n = pu / hw_n, hw = pu - n * hw_n;
                     ldv<T, V>(dy + p * Cout + cg * V, g[u]);
 #pragma unroll
-                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = ci < Cin ? x[(n * Cin + ci) * HW + hw] : 0.f;
+                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = ci < Cin ? x[((size_t)n * Cin + ci) * hw_n + hw] : 0.f;
                 } else {
 #pragma unroll
                     for (int e = 0; e < V; ++e) g[u][e] = 0.f;
@@ -205,7 +217,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         float o[MAXHC];
 #pragma unroll
-        for (int co = 0; co < MAXHC; ++co) o[co] = co < Cout ? b[co] : 0.f;
+        for (int co = 0; co < MAXHC; ++co) o[co] = b[co < Cout ? co : Cout - 1];
+#pragma unroll
+        for (int co = 0; co < MAXHC; ++co) o[co] = co < Cout ? o[co] : 0.f;
         for (int c = 0; c < Cin; c += V) {
             float v[V];
             ldv<T, V>(x + p * Cin + c, v);
@@ -216,10 +230,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
                     for (int e = 0; e < V; ++e) o[co] = fmaf(w[co * Cin + c + e], v[e], o[co]);
                 }
         }
-        const long n = p / HW, hw = p % HW;
+        const unsigned hw_n = (unsigned)HW, n = (unsigned)p / hw_n, hw = (unsigned)p - n * hw_n;  // 32-bit divide
 #pragma unroll
         for (int co = 0; co < MAXHC; ++co)
-            if (co < Cout) logits[(n * Cout + co) * HW + hw] = o[co];
+            if (co < Cout) logits[((size_t)n * Cout + co) * hw_n + hw] = o[co];
     }
 }
 
@@ -245,7 +259,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int co = 0; co < MAXHC; ++co)
 #pragma unroll
-            for (int e = 0; e < V; ++e) wv[co][e] = co < Cout ? w[co * Cin + cg * V + e] : 0.f;
+            for (int e = 0; e < V; ++e) wv[co][e] = w[(co < Cout ? co : Cout - 1) * Cin + cg * V + e];
+#pragma unroll
+        for (int co = 0; co < MAXHC; ++co)
+#pragma unroll
+            for (int e = 0; e < V; ++e) wv[co][e] = co < Cout ? wv[co][e] : 0.f;
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix) end = npix;
@@ -256,10 +274,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
             for (int u = 0; u < UNR; ++u) {
                 const long p = p0 + (long)u * PL;
                 if (p < end) {
-                    const long n = p / HW, hw = p % HW;
+                    const unsigned hw_n = (unsigned)HW, n = (unsigned)p / hw_n, hw = (unsigned)p - n * hw_n;  // 32-bit divide
                     ldv<T, V>(x + p * Cin + cg * V, xv[u]);
 #pragma unroll
-                    for (int co = 0; co < MAXHC; ++co) g[u][co] = co < Cout ? dl[(n * Cout + co) * HW + hw] : 0.f;
+                    for (int co = 0; co < MAXHC; ++co)
+                        g[u][co] = dl[((size_t)n * Cout + (co < Cout ? co : Cout - 1)) * hw_n + hw];
+#pragma unroll
+                    for (int co = 0; co < MAXHC; ++co) g[u][co] = co < Cout ? g[u][co] : 0.f;
                 } else {
 #pragma unroll
                     for (int e = 0; e < V; ++e) xv[u][e] = 0.f;
@@ -453,7 +474,7 @@ inline RedGeo red_geo(long npix, int C, int V) {
     g.CG = C / V;
     g.PL = 256 / g.CG;
     long nb = (npix + (long)g.PL * 8 - 1) / ((long)g.PL * 8);
-    if (nb > 512) nb = 512;
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     g.nblk = (int)nb;
     g.ppb = (npix + nb - 1) / nb;
@@ -491,6 +512,7 @@ extern "C" int hipseg_stem_fwd(int dtype, const float* x, const float* w, const 
     HS_REQUIRE(x && w && b && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "stem_fwd: bad arguments");
     const int V = vec_for(Cout, dtype);
     const long HW = (long)H * W;
+    HS_REQUIRE((long)B * HW * (Cout / V) < (1l << 31), "stem_fwd: more than 2^31 (pixel, channel-vector) items");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
         hipLaunchKernelGGL((stem_fwd_kernel<T_, V_>), dim3(grid_for(B * HW * (Cout / V_))), dim3(256), 0, s, x, w, b,
@@ -502,7 +524,7 @@ extern "C" int hipseg_stem_fwd(int dtype, const float* x, const float* w, const 
 
 extern "C" int hipseg_stem_bwd_blocks(int B, int H, int W) {
     long nb = ((long)B * H * W + 255) / 256;
-    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 
 extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float* partial, float* dw, float* db, int B,
@@ -513,6 +535,7 @@ extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float*
     const int V = vec_for(Cout, dtype);
     HS_REQUIRE(Cout / V <= 256 && Cout <= 2048, "stem_bwd: unsupported Cout %d", Cout);
     const long HW = (long)H * W, npix = (long)B * HW;
+    HS_REQUIRE(npix < (1l << 31), "stem_bwd: more than 2^31 pixels");
     RedGeo g;
     g.CG = Cout / V;
     g.PL = 256 / g.CG;
@@ -537,6 +560,7 @@ extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const f
     HS_REQUIRE(Cout >= 1 && Cout <= MAXHC, "head_fwd: out_channels %d unsupported (1..%d)", Cout, MAXHC);
     const int V = vec_for(Cin, dtype);
     const long HW = (long)H * W;
+    HS_REQUIRE((long)B * HW < (1l << 31), "head_fwd: more than 2^31 pixels");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
         hipLaunchKernelGGL((head_fwd_kernel<T_, V_>), dim3(grid_for(B * HW)), dim3(256), 0, s, (const T_*)x, w, b,
@@ -548,7 +572,7 @@ extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const f
 
 extern "C" int hipseg_head_bwd_blocks(int B, int H, int W) {
     long nb = ((long)B * H * W + 255) / 256;
-    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));  // (1024 measured slower: the per-block LDS tail dominates)
 }
 
 extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, const float* w, void* dx,
@@ -560,6 +584,7 @@ extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, c
     const int V = vec_for(Cin, dtype);
     HS_REQUIRE(Cin / V <= 256 && Cin + 1 <= 2048, "head_bwd: unsupported Cin %d", Cin);
     const long HW = (long)H * W, npix = (long)B * HW;
+    HS_REQUIRE(npix < (1l << 31), "head_bwd: more than 2^31 pixels");
     RedGeo g;
     g.CG = Cin / V;
     g.PL = 256 / g.CG;

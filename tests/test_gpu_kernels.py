@@ -151,7 +151,9 @@ def test_conv3_dgrad_wgrad(hs, prec, td, dt, case):
     assert err <= 2e-4 * max(1.0, float(g.abs().max())), f"wgrad max err {float(err):.3e} vs scale {float(g.abs().max()):.3e}"
 
 
-CONVT_CASES = [(2, 16, 8, 8, 8), (1, 64, 32, 4, 12), (1, 128, 64, 16, 16), (1, 12, 6, 5, 7)]
+CONVT_CASES = [(2, 16, 8, 8, 8), (1, 64, 32, 4, 12), (1, 128, 64, 16, 16), (1, 12, 6, 5, 7),
+               # the one-tap GEMM kernel (C0 % 64 == 0, N % 128 == 0): ragged tiles, several images, K chunks across taps
+               (2, 256, 128, 7, 9), (1, 512, 256, 3, 5), (3, 64, 64, 18, 17)]
 
 
 @pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
