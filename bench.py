@@ -159,6 +159,11 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    # stdout carries exactly ONE line, the JSON: everything else that libraries print there while the benchmark runs
+    # (RCCL writes its version banner to stdout when a communicator is created) is re-routed to stderr at the fd level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -270,6 +275,8 @@ def main():
                 net.broadcast_buffers_now()
             loss = step()
         torch.cuda.synchronize()
+        if ddp:
+            HipDDP.quiesce_before_capture()  # let the RCCL watchdog retire the eager warm-up collectives first
         run = None
         if not split:
             # ONE hipGraph for the whole step.  N > 1: the hooks fire during capture, so each bucket's all-reduce is
@@ -395,6 +402,8 @@ def main():
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

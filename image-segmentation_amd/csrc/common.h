@@ -34,6 +34,12 @@ void hipseg_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize), done once per (device, kernel) and thread-safe (pack.hip)
+int hs_set_max_lds(const void* kernel, size_t bytes);
+// compute units of the current device, cached per device; 256 (MI355X) when no device is visible (host-only geometry
+// queries in the build container)
+int device_cus();
+
 // ---------------------------------------------------------------- per-dtype traits
 template <typename T>
 struct VecOf;

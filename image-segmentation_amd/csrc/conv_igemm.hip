@@ -19,7 +19,7 @@
 //   conv3_wstat_kernel     3x3, <= 64 channels on both sides, >= 1024 tiles: weights in registers, persistent
 //   conv3_ring64_kernel    3x3, 128-wide tiles, K % 32 == 0: activation super-chunks + register-staged weights
 //   conv_igemm_dma_kernel  every other vector-aligned shape / mode (ring of 16-channel chunks)
-//   conv_igemm_pers_kernel opt-in persistent form of the ring kernel (HIPSEG_PERSISTENT=1; measured slower)
+//   gemm1_kernel           ConvTranspose2d forward / data gradient with K >= 256: one-tap GEMM, pixel-major stages
 //   conv_igemm_kernel      fp32 and channel counts that are not multiples of 8 (register-staged, single buffer)
 #include <stdlib.h>
 
@@ -77,9 +77,7 @@ struct ConvArgs {
     int K, Kp, N, Np;
     int tiles_x, tiles_y, ntn;
     int vec_ok;
-    int stagger;  // initial s_sleep count (x ~3.5 us) of every second "generation" of workgroups: de-phases the two
-                  // workgroups that share a CU so one's epilogue stores overlap the other's MFMA phase
-    int ncu;
+    int ncu;      // compute units of the current device (grid of the persistent weights-stationary kernel)
     int debug;  // ablation bits (HIPSEG_IGEMM_DEBUG): 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip epilogue
     int xcd;    // XCD-aware workgroup order: 0 off, else grid / 8 (see xcd_block)
 };
@@ -619,9 +617,6 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>
     for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
 
     const int nchunks = p.Kp / KC;
-    if (p.stagger && ((blockIdx.x / p.ncu) & 1)) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // prologue: the activation pieces of the first DIST chunks go out at once; weight chunk 0 through registers
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
@@ -1060,255 +1055,6 @@ __global__ __launch_bounds__(512, 1) void conv3_ring64_kernel(ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Persistent form of the 256x128 bf16 kernel (one 512-thread workgroup per CU walks a strided list of
-// output tiles).  The (tile, K-chunk) sequence is ONE software pipeline: the LDS-DMA of the next tile's
-// first chunk is in flight while the last chunk of the current tile computes (no per-tile prologue bubble),
-// and a finished tile is PARKED as bf16 in a wave-private LDS region and drained to HBM with 16-byte stores
-// at the top of the next iteration, so its stores retire under the next tile's MFMAs instead of in an
-// exposed epilogue.  LDS: 2 x 48 KiB ring + 64 KiB park = the full 160 KiB of the CU.
-// Needs vector-aligned channels (C0, C1, N0, N1 multiples of 8).
-// THT = tile rows: 16 (256x128 tile) or 32 (512-row "tall" tile for the <= 64-channel full-resolution layers: the
-// weight chunk is amortised over twice the pixels and every wave still owns a 64-row x 64/32-channel block).
-template <int MODE, int BN, int THT>
-__global__ __launch_bounds__(512, 2) void conv_igemm_pers_kernel(ConvArgs p, int total_tiles) {
-    typedef bf16 T;
-    constexpr int NW = 8, KC = 16, KG = 2;
-    constexpr int HW = Geo<MODE>::HW, NT = Geo<MODE>::NT;
-    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT), NPIX = HH * HW;
-    constexpr int NPIXP = (NPIX + 63) / 64 * 64;
-    constexpr int WN = WG<BN, NW>::WN, WM = NW / WN, MT = (THT * TW / WM) / 32, NTL = WG<BN, NW>::NTL;
-    static_assert(MT == 2 && (NTL == 1 || NTL == 2), "wave tile 64 rows x 32/64 channels");
-    constexpr int TN = 32 * NTL, VPR = TN / 8;  // channels / 16-byte vectors per row of the wave tile
-    constexpr int A_BYTES = KG * NPIXP * 16, B_BYTES = NT * KG * BN * 16, BUF = A_BYTES + B_BYTES;
-    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
-    constexpr int NAW = (NA + NW - 1) / NW, NBW = (NB + NW - 1) / NW;
-    constexpr int RUNB = BN * 16;
-    constexpr int NPCW = NAW + NBW, PPT = (NPCW + NT - 1) / NT;
-    constexpr int PARKW = 64 * TN * 2;  // bytes of one wave's parked 64 x TN bf16 tile
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    unsigned char* park = smem + 2 * BUF + wave * PARKW;
-
-    const T* in0 = reinterpret_cast<const T*>(p.in0);
-    const T* in1 = reinterpret_cast<const T*>(p.in1);
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.wp);
-    const T* zero = reinterpret_cast<const T*>(&g_zero16);
-    T* out0 = reinterpret_cast<T*>(p.out0);
-    T* out1 = reinterpret_cast<T*>(p.out1);
-    const int kgp = p.Kp / 8;
-    const int nchunks = p.Kp / KC;
-    const int step = gridDim.x;
-
-    // ---- issue side state (runs one chunk ahead of the compute side)
-    int itile = blockIdx.x, ikc = 0, in0_ = 0;
-    long apix[NAW];
-    int aoct[NAW];
-    auto setup_issue = [&](int id) {
-        const int ntile = id % p.ntn, mtile = id / p.ntn;
-        const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
-        const int img = mtile / (p.tiles_x * p.tiles_y);
-        in0_ = ntile * BN;
-        int oy = ty * THT, ox = tx * TW;
-        if (MODE == HIPSEG_CONV3) {
-            oy -= 1;
-            ox -= 1;
-        } else if (MODE == HIPSEG_CONV2S2) {
-            oy *= 2;
-            ox *= 2;
-        }
-#pragma unroll
-        for (int j = 0; j < NAW; ++j) {
-            const int s = j * NW + wave;
-            aoct[j] = s / (NPIXP / 64);
-            const int pix = (s % (NPIXP / 64)) * 64 + lane;
-            const int iy = oy + pix / HW, ix = ox + pix % HW;
-            const bool ok = s < NA && pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            apix[j] = ok ? ((long)img * p.Hi + iy) * p.Wi + ix : -1;
-        }
-    };
-    auto issue_piece = [&](int buf, int idx) {
-        unsigned char* base = smem + buf * BUF;
-        const int c0 = ikc * KC;
-        if (idx < NAW) {
-            const int s = idx * NW + wave;
-            if (s < NA) {
-                const int c = c0 + aoct[idx] * 8;
-                const T* src = zero;
-                if (apix[idx] >= 0 && c < p.K)
-                    src = (c < p.C0) ? in0 + apix[idx] * p.C0 + c : in1 + apix[idx] * p.C1 + (c - p.C0);
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + s * 1024), 16, 0, 0);
-            }
-        } else {
-            const int s = (idx - NAW) * NW + wave;
-            if (s < NB) {
-                const int b = s * 1024 + lane * 16;
-                const int run = b / RUNB, off = b % RUNB;
-                const int tap = run / KG, kgl = run % KG;
-                const unsigned char* src = wp + (((size_t)tap * kgp + c0 / 8 + kgl) * p.Np + in0_) * 16 + off;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + s * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto advance_issue = [&]() {
-        if (++ikc == nchunks) {
-            ikc = 0;
-            itile += step;
-            if (itile < total_tiles) setup_issue(itile);
-        }
-    };
-
-    // ---- compute side state
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int hbase[MT], ncol[NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int py = 2 * (wm * MT + i) + (r >> 4), px = sub_px<MODE>(r);
-        hbase[i] = MODE == HIPSEG_CONV2S2 ? (2 * py) * HW + 2 * px : py * HW + px;
-    }
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) ncol[j] = wn * (BN / WN) + j * 32 + r;
-
-    int ctile = blockIdx.x, kc = 0;
-    bool pending = false;
-    int d_img = 0, d_y0 = 0, d_x0 = 0, d_n0 = 0;  // coordinates of the parked tile
-
-    auto park_tile = [&]() {
-        const int ntile = ctile % p.ntn, mtile = ctile / p.ntn;
-        const int tx = mtile % p.tiles_x, ty = (mtile / p.tiles_x) % p.tiles_y;
-        d_img = mtile / (p.tiles_x * p.tiles_y);
-        d_y0 = ty * THT;
-        d_x0 = tx * TW;
-        d_n0 = ntile * BN;
-        bf16* pk = reinterpret_cast<bf16*>(park);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            const int n = d_n0 + ncol[j];
-            const bool nok = n < p.N;
-            int co = n;
-            if (MODE == HIPSEG_CONVT) co = n % p.N0;
-            const float bv = (nok && p.bias) ? p.bias[co] : 0.f;
-            float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int yb = d_y0 + 2 * (wm * MT + i);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[i][j][e] + bv;
-                    pk[(i * 32 + rr) * TN + j * 32 + r] = (bf16)v;
-                    if (nok && yb + (rr >> 4) < p.H && d_x0 + sub_px<MODE>(rr) < p.W) {
-                        ssum += v;
-                        ssq += v * v;
-                    }
-                    acc[i][j][e] = 0.f;
-                }
-            }
-            if (p.stats) {
-                ssum += __shfl_xor(ssum, 32, 64);
-                ssq += __shfl_xor(ssq, 32, 64);
-                // statistics rows are per 64 output pixels of the 16-row tile grid (4 per 16x16 tile)
-                const int ty16 = ty * (THT / 16) + wm / 4, tiles_y16 = (p.H + 15) / 16;
-                if (h == 0 && nok && ty16 < tiles_y16) {
-                    const size_t row = (((size_t)d_img * tiles_y16 + ty16) * p.tiles_x + tx) * 4 + (wm & 3);
-                    p.stats[(row * 2 + 0) * p.N + n] = ssum;
-                    p.stats[(row * 2 + 1) * p.N + n] = ssq;
-                }
-            }
-        }
-        pending = true;
-    };
-    auto drain_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < VPR; ++it) {
-            const int v = it * 64 + lane;
-            const int row = v / VPR, cv = v % VPR;
-            const int i = row >> 5, rr = row & 31;
-            const int y = d_y0 + 2 * (wm * MT + i) + (rr >> 4), x = d_x0 + sub_px<MODE>(rr);
-            const int n = d_n0 + wn * (BN / WN) + cv * 8;
-            const uint4 val = *reinterpret_cast<const uint4*>(park + row * (TN * 2) + cv * 16);
-            if (y < p.H && x < p.W && n < p.N) {
-                T* dst;
-                if (MODE == HIPSEG_CONVT) {
-                    const int ab = n / p.N0, co = n - ab * p.N0;
-                    const long opix = ((long)d_img * (2 * p.H) + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-                    dst = out0 + opix * p.N0 + co;
-                } else {
-                    const long opix = ((long)d_img * p.H + y) * p.W + x;
-                    dst = (n < p.N0) ? out0 + opix * p.N0 + n : out1 + opix * p.N1 + (n - p.N0);
-                }
-                *reinterpret_cast<uint4*>(dst) = val;
-            }
-        }
-        pending = false;
-    };
-
-    const int my_tiles = (total_tiles - (int)blockIdx.x + step - 1) / step;
-    const int total_flat = my_tiles * nchunks;
-    setup_issue(itile);
-#pragma unroll
-    for (int q = 0; q < NPCW; ++q) issue_piece(0, q);
-    advance_issue();
-
-    for (int f = 0; f < total_flat; ++f) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk f landed (and the previous tile's drain retired)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (pending) drain_tile();
-        const bool more = f + 1 < total_flat;
-        const int nbuf = (f + 1) & 1;
-        const unsigned char* sA = smem + (f & 1) * BUF;
-        const unsigned char* sB = sA + A_BYTES;
-        bf16x8 bf[2][NTL], af[2][MT];
-        auto fetch = [&](int slot, int tap) {
-            const int toff = tap_off<MODE>(tap);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                bf[slot][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(tap * KG + h) * BN + ncol[j]) * 16);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                af[slot][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)h * NPIXP + hbase[i] + toff) * 16);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][0], bf[tap & 1][j], acc[0][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < NT) fetch((tap + 1) & 1, tap + 1);
-            if (more) {
-#pragma unroll
-                for (int q = tap * PPT; q < (tap + 1) * PPT && q < NPCW; ++q) issue_piece(nbuf, q);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][1], bf[tap & 1][j], acc[1][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) advance_issue();
-        if (++kc == nchunks) {
-            park_tile();
-            kc = 0;
-            ctile += step;
-        }
-    }
-    if (pending) drain_tile();
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Weights-stationary 3x3 kernel for the <= 64-channel layers (the full-resolution layers of the U-Net).
 // There the implicit GEMM is short (K = 9 x 32..64) and the ring kernel spends as many LDS-DMA pieces on
 // re-fetching the weight chunk for every pixel tile as on the activations -- and LDS-DMA moves only ~11 B/clk
@@ -1572,14 +1318,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
 template <int KCH, int NB>
 int launch_wstat(const ConvArgs& a, hipStream_t s) {
     typedef WsGeo<KCH, NB> G;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false>), (size_t)G::LDS)) return rc;
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, true>), (size_t)G::LDS)) return rc;
     const int tiles_y8 = cdiv(a.H, G::THS);
     const long total = (long)a.B * a.tiles_x * tiles_y8;
     const long grid = 2 * a.ncu;  // wstat_grid(): total >= 4 * ncu
@@ -1593,43 +1333,6 @@ int launch_wstat(const ConvArgs& a, hipStream_t s) {
     return HIPSEG_OK;
 }
 
-template <int MODE, int BN, int THT>
-int launch_pers(const ConvArgs& a0, hipStream_t s) {
-    constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT);
-    constexpr int NPIXP = (HH * Geo<MODE>::HW + 63) / 64 * 64, NT = Geo<MODE>::NT;
-    constexpr size_t lds = 2 * (size_t)(2 * NPIXP * 16 + NT * 2 * BN * 16) + 8 * 64 * (BN / WG<BN, 8>::WN) * 2;
-    ConvArgs a = a0;
-    a.tiles_y = cdiv(a.H, THT);
-    static_assert(lds <= 163840, "LDS budget");
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            hipseg_set_error("conv_igemm: cannot query the device");
-            return HIPSEG_EHIP;
-        }
-        ncu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pers_kernel<MODE, BN, THT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    const long total = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
-    const int grid = (int)(total < ncu ? total : ncu);
-    hipLaunchKernelGGL((conv_igemm_pers_kernel<MODE, BN, THT>), dim3(grid), dim3(512), lds, s, a, (int)total);
-    HS_LAUNCH_CHECK("conv_igemm_pers");
-    return HIPSEG_OK;
-}
-
-template <int BN>
-int launch_pers_mode(const ConvArgs& a, int mode, hipStream_t s) {
-    switch (mode) {
-        case HIPSEG_CONV3: return launch_pers<HIPSEG_CONV3, BN, 16>(a, s);
-        case HIPSEG_CONV1: return launch_pers<HIPSEG_CONV1, BN, 16>(a, s);
-        case HIPSEG_CONV2S2: return launch_pers<HIPSEG_CONV2S2, BN, 16>(a, s);
-        default: return launch_pers<HIPSEG_CONVT, BN, 16>(a, s);
-    }
-}
-
 template <int MODE, int BN, int THT = 16>
 int launch_dma(const ConvArgs& a0, hipStream_t s) {
     constexpr int HH = MODE == HIPSEG_CONV3 ? THT + 2 : (MODE == HIPSEG_CONV2S2 ? 2 * THT : THT);
@@ -1641,12 +1344,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     static_assert(lds <= 163840, "LDS budget");
     ConvArgs a = a0;
     a.tiles_y = cdiv(a.H, THT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN, THT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN, THT>), (size_t)lds)) return rc;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
@@ -1659,12 +1357,7 @@ template <int MODE>
 int launch_gemm1(const ConvArgs& a0, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)(256 * 64 * 2 + 8 * 128 * 16);  // ring (144 KiB) > epilogue scratch (64 KiB)
     ConvArgs a = a0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1_kernel<MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&gemm1_kernel<MODE>), (size_t)lds)) return rc;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
@@ -1678,12 +1371,7 @@ int launch_ring64(const ConvArgs& a0, hipStream_t s) {
     typedef A64Geo<THT, SO> G;
     ConvArgs a = a0;
     a.tiles_y = cdiv(a.H, THT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_ring64_kernel<THT, SO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_ring64_kernel<THT, SO>), (size_t)G::LDS)) return rc;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
@@ -1748,13 +1436,13 @@ int wstat_grid(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H
     const int K = C0 + C1, N = N0 + N1, Kp = (K + 15) / 16 * 16;
     if (!(N == 32 || N == 64) || !(Kp == 32 || Kp == 64)) return 0;
     const long total = (long)B * cdiv(W, TW) * cdiv(H, 8);
-    const int ncu = 256;
+    const int ncu = device_cus();
     if (total < 4 * ncu) return 0;
     return 2 * ncu;
 }
 
 int bn_for(int N) {
-    static const int bn_max = getenv("HIPSEG_BN_MAX") ? atoi(getenv("HIPSEG_BN_MAX")) : 128;  // tuning experiments
+    const int bn_max = 128;
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     return bn > bn_max ? bn_max : bn;
 }
@@ -1817,26 +1505,11 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
     static const int dbg = getenv("HIPSEG_IGEMM_DEBUG") ? atoi(getenv("HIPSEG_IGEMM_DEBUG")) : 0;
     a.debug = dbg;
-    static const int stg = getenv("HIPSEG_STAGGER") ? atoi(getenv("HIPSEG_STAGGER")) : 0;
-    a.stagger = stg;
-    a.ncu = 256;
+    a.ncu = device_cus();
     a.xcd = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
-        // The persistent variants (cross-tile pipeline + parked stores, 512-row tall tiles) pass every parity
-        // test but measured 2-3 % SLOWER than the plain 3-deep-ring kernel on the full training step
-        // (same box, back to back), so they are opt-in: HIPSEG_PERSISTENT=1.
-        static const bool no_pers = getenv("HIPSEG_PERSISTENT") == nullptr;
-        // persistent form for the 256x128 tile; the 64/32-wide tiles run two smaller workgroups per CU instead
-        // (measured faster than a persistent 8-wave 256x64 tile)
-        if (a.vec_ok && !no_dma && !no_pers && N0 % 8 == 0 && N1 % 8 == 0) {
-            if (bn == 128) return launch_pers_mode<128>(a, mode, s);
-            // <= 64-channel 3x3 layers (full resolution in the U-Net): persistent 512-row tall tiles
-            static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
-            if (mode == HIPSEG_CONV3 && H >= 32 && !no_tall)
-                return bn == 64 ? launch_pers<HIPSEG_CONV3, 64, 32>(a, s) : launch_pers<HIPSEG_CONV3, 32, 32>(a, s);
-        }
         if (wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W)) {
             if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
             return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
@@ -1854,7 +1527,7 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
                 a.N % 128 == 0 && a.Kp == C0 && N0 % 8 == 0 && (mode == HIPSEG_CONVT ? C0 : 4 * C0) >= 256)
                 return mode == HIPSEG_CONVT ? launch_gemm1<HIPSEG_CONVT>(a, s) : launch_gemm1<HIPSEG_CONV2S2>(a, s);
             // 512-pixel tall tiles for 3x3 layers with enough of them to fill the chip (1 or 2 workgroups per CU)
-            static const bool no_tall = getenv("HIPSEG_NO_TALL") != nullptr;
+            const bool no_tall = false;
             const long tall_wgs = (long)a.B * a.tiles_x * cdiv(H, 32) * a.ntn;
             // 128-wide tiles whose K splits into whole activation super-chunks inside one source tensor
             static const bool no_r64 = getenv("HIPSEG_NO_RING64") != nullptr;

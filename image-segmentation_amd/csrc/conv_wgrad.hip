@@ -515,14 +515,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
 template <int NT, int UB, int VB>
 int launch_dma(const WgArgs& a, hipStream_t s) {
     constexpr size_t lds = DmaGeo<NT, UB, VB>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, false>), (size_t)lds)) return rc;
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad_dma_kernel<NT, UB, VB, true>), (size_t)lds)) return rc;
     const dim3 grid((unsigned)(a.S * a.UT * a.VT));
     if (a.debug)
         hipLaunchKernelGGL((wgrad_dma_kernel<NT, UB, VB, true>), grid, dim3(512), lds, s, a);
@@ -609,7 +603,8 @@ Plan make_plan(int mode, int CU, int CV, int B, int H, int W) {
     p.ntiles = B * p.tiles_x * p.tiles_y;
     // workgroups per launch ~ CUs (bf16: the double-buffered DMA kernel runs one 146-KB workgroup per CU;
     // f32: two single-buffered ones).  Fewer, fatter splits also keep the slab traffic small.
-    int S = (sizeof(T) == 2 ? 256 : 512) / (p.UT * p.VT);
+    const int ncu = device_cus();
+    int S = (sizeof(T) == 2 ? ncu : 2 * ncu) / (p.UT * p.VT);
     if (S < 1) S = 1;
     if (S > p.ntiles) S = p.ntiles;
     p.S = S;
@@ -625,12 +620,7 @@ int launch(const WgArgs& a, hipStream_t s) {
     constexpr int HALO = NT == 9 ? 1 : 0;
     constexpr int NPP = (WT<T>::TH + 2 * HALO) * (TW + 2 * HALO), NPQ = WT<T>::TH * TW;
     const size_t lds = ((size_t)NPP * WT<T>::UC + (size_t)NPQ * WT<T>::VC) * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, NT>), (size_t)lds)) return rc;
     hipLaunchKernelGGL((wgrad_kernel<T, NT>), dim3((unsigned)(a.S * a.UT * a.VT)), dim3(256), lds, s, a);
     HS_LAUNCH_CHECK("conv_wgrad");
     return HIPSEG_OK;

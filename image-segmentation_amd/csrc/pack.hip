@@ -12,6 +12,41 @@ void hipseg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* hipseg_last_error(void) { return g_err; }
+
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
+
+int hs_set_max_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return HIPSEG_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        hipseg_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu): %s", bytes, hipGetErrorString(e));
+        return HIPSEG_EHIP;
+    }
+    done.insert({dev, kernel});
+    return HIPSEG_OK;
+}
+
+int device_cus() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t prop;
+    const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev] = n;
+    return n;
+}
 extern "C" int hipseg_abi_version(void) { return 1; }
 
 namespace {

@@ -123,6 +123,20 @@ class HipDDP(nn.Module):
                     p._hipseg_slot = (b.flat, o)
                     self._slotted.append(p)
 
+    @staticmethod
+    def quiesce_before_capture(seconds=0.3):
+        """Call before capturing a step that contains collectives into a hipGraph.  torch's ProcessGroupNCCL watchdog
+        thread polls the end events of the EAGER collectives issued so far (warm-up steps) until it has seen them
+        complete; a capture pulls the process group's internal RCCL stream into capture mode, and HIP then refuses
+        `hipEventQuery` on an event whose stream is capturing (hipErrorCapturedEvent) -- the watchdog aborts the
+        process.  Draining the device and giving the watchdog (100 ms poll interval) time to retire its list removes
+        the race: collectives issued DURING capture are never handed to the watchdog."""
+        import time
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        time.sleep(seconds)
+
     def remove_hooks(self):
         """detach this reducer from the module's parameters (before wrapping the same module again)."""
         for h in self._hook_handles:

@@ -7,6 +7,7 @@ reference's (B, C, H, W) shapes.
 """
 import contextlib
 import os
+import weakref
 
 import torch
 
@@ -138,7 +139,7 @@ def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H,
 # a forward (prepack); the per-layer helpers below first look the weight up in that cache (same storage, same
 # version counter) and only pack individually when it is not there (stand-alone block calls, tests).
 _PACKED = {}   # (data_ptr, shape, dt) -> (version, wp, wpt)
-_PLANS = {}    # (id(module), dt) -> _PackPlan
+_PLANS = weakref.WeakKeyDictionary()  # module -> {dt: _PackPlan}; dies with the module (no id() reuse aliasing)
 
 
 class _PackPlan:
@@ -169,8 +170,8 @@ def prepack(module, prec):
     if not params:
         return
     ptrs = tuple(w.data_ptr() for w, _ in params)
-    key = (id(module), dt)
-    plan = _PLANS.get(key)
+    plans = _PLANS.setdefault(module, {})
+    plan = plans.get(dt)
     if plan is None or plan.ptrs != ptrs:
         dev = params[0][0].device
         td = _tdtype(prec)
@@ -189,7 +190,7 @@ def prepack(module, prec):
                 cin, cout, k = w.shape[0], w.shape[1], 2
             L.pack_desc_fill(ctypes.addressof(host), i, ptr(w), ptr(wp), ptr(wpt), kind, dt, cout, cin, k)
         plan.desc = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
-        _PLANS[key] = plan
+        plans[dt] = plan
     L.pack_batch(ptr(plan.desc), plan.n, dt, plan.max_total, _stream())
     for (w, _), (wp, wpt) in zip(plan.params, plan.bufs):
         _PACKED[(w.data_ptr(), tuple(w.shape), dt)] = (w._version, wp, wpt)

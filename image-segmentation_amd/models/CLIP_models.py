@@ -12,11 +12,15 @@ class ClipUnet(UNet):
     """UNet trunk whose bottleneck output is REPLACED by CrossAttentionFusion(bottleneck, clip)
     (reference: CLIP_models.py:115-134; `activation` is stored but never applied there).
     Because the fusion output does not depend on the bottleneck features (degenerate attention),
-    the bottleneck ConvBlock contributes nothing to the output or to any gradient; it is kept for
-    state_dict compatibility and skipped in forward unless `run_dead_bottleneck` is set (the
-    reference still updates its BatchNorm running statistics in train mode)."""
+    the bottleneck ConvBlock contributes nothing to the output or to any gradient.  The reference
+    still runs it, which in train mode updates its BatchNorm running statistics and
+    `num_batches_tracked` -- state that ends up in checkpoints.  With `run_dead_bottleneck` (default
+    True) the block's FORWARD is therefore executed in train mode, under no_grad (nothing is saved,
+    nothing runs in backward, its parameters receive no gradient -- the reference's are exactly zero
+    up to rounding), so a saved state_dict matches the reference's; in eval mode it changes no state
+    and is skipped.  Set it to False to drop the ~4 % of step time it costs."""
 
-    run_dead_bottleneck = False
+    run_dead_bottleneck = True
 
     def __init__(self, out_channels=3, in_channels=3, activation=nn.Identity(), clip_feature_extractor=None):
         nn.Module.__init__(self)
@@ -33,8 +37,9 @@ class ClipUnet(UNet):
         clip_features = self.clip_feature_extractor(X)
 
         def fuse(h, skips):
-            if self.run_dead_bottleneck:
-                h = self.bottleneck(h)
+            if self.run_dead_bottleneck and self.bottleneck.training:
+                with torch.no_grad():
+                    self.bottleneck(h)  # BatchNorm bookkeeping only (see the class docstring)
             B, _, H, W = h.shape
             ref = h.new_empty((B, 512, H, W), device="meta")
             return self.cross_attention_fusion(ref, clip_features)

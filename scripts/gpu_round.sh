@@ -5,7 +5,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; rc=$?
 tail -5 $out/pytest.log
-python scripts/diag_c5.py
+
 python bench.py --no-cpu-baseline > $out/bench_n1.json 2> $out/bench_n1.err || { tail -5 $out/bench_n1.err; exit 1; }
 cat $out/bench_n1.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_event_median'], d.get('roofline',{}).get('frac'))"
 HIPSEG_BENCH_FORCE_DDP=1 python bench.py --no-cpu-baseline --no-roofline > $out/bench_ddp_graph.json 2> $out/bench_ddp_graph.err || { tail -5 $out/bench_ddp_graph.err; exit 1; }

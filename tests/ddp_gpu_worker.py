@@ -1,0 +1,193 @@
+"""WORKER of tests/test_gpu_ddp.py (run as a child process: `python tests/ddp_gpu_worker.py <case>`; a failure inside a
+hipGraph capture that holds collectives can abort the process from the RCCL watchdog thread, which must not take the
+whole pytest session with it).
+
+HipDDP on the real RCCL backend (`nccl`), one rank, EVERY collective still issued
+(`force_collectives=True`): the autograd hook -> bucket copy -> event -> side-stream all-reduce(AVG) ->
+join path, eagerly and captured inside one hipGraph, must leave exactly the gradients of the plain
+(non-DDP) step.  Replaces `DDP(model, device_ids=[rank])` of the reference
+(scripts/train_distributed.py:35, models/model_wrappers.py:968-980).  The >1-rank arithmetic is
+covered on CPU by tests/test_cpu_host.py (gloo, world_size 2)."""
+import os
+import sys
+import traceback
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "image-segmentation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def _data(B=2, S=64):
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, S, S, generator=g).cuda()
+    t = torch.randint(0, 3, (B, S, S), generator=g).cuda()
+    return x, t
+
+
+def _step(net, crit, x, t, scale=1.0):
+    with torch.autocast("cuda"):
+        loss = crit(net(x), t)
+    (loss * scale).backward()
+    return loss
+
+
+def case_hook_path_matches_plain_backward_bitwise(pg):
+    from hipseg.ddp import HipDDP
+    from models.losses import HybridLoss
+    from models.UNet import UNet
+
+    torch.manual_seed(3)
+    model = UNet().cuda().train()
+    crit = HybridLoss()
+    x, t = _data()
+    _step(model, crit, x, t)  # plain step
+    torch.cuda.synchronize()
+    ref = [p.grad.detach().clone() for p in model.parameters()]
+    rm_ref = model.enc1.block[0].conv[1].running_mean.clone()
+
+    model.zero_grad(set_to_none=True)
+    ddp = HipDDP(model, device_ids=[0], first_bucket_mb=0.05, bucket_cap_mb=4.0, force_collectives=True)
+    assert ddp.module is model and len(ddp.buckets) >= 4
+    nparams = len(ref)
+    for it, set_none in enumerate((True, False, True)):
+        before = dict(ddp.stats)
+        ddp.zero_grad(set_to_none=set_none)
+        _step(ddp, crit, x, t)
+        torch.cuda.synchronize()
+        assert ddp.stats["hook_calls"] - before["hook_calls"] == nparams
+        assert ddp.stats["buckets_reduced"] - before["buckets_reduced"] == len(ddp.buckets)
+        assert ddp.stats["comm_stream_collectives"] - before["comm_stream_collectives"] == len(ddp.buckets)
+        for p, r in zip(model.parameters(), ref):
+            assert torch.equal(p.grad, r), f"iteration {it}: gradient differs from the plain step"
+            assert any(p.grad.data_ptr() == v.data_ptr() for b in ddp.buckets for v in b.views)
+    assert ddp.stats["zero_filled_slots"] == 0
+    # the HIP backward kernels wrote straight into the bucket slots: no hook-side copies were needed for them
+    assert ddp.stats["hook_copies"] == 0 and all(hasattr(p, "_hipseg_slot") for p in model.parameters())
+    ddp.remove_hooks()
+    assert not any(hasattr(p, "_hipseg_slot") for p in model.parameters())
+    # BN buffers were re-pointed into the flat broadcast tensor and keep being updated by the kernels
+    assert not torch.equal(model.enc1.block[0].conv[1].running_mean, rm_ref)
+    lo = ddp._flat_buffers.data_ptr()
+    assert lo <= model.enc1.block[0].conv[1].running_mean.data_ptr() < lo + ddp._flat_buffers.numel() * 4
+
+
+def case_overlapped_allreduce_captured_in_one_hipgraph(pg):
+    """the benchmarked N > 1 form: zero_grad + fwd + loss + scaled bwd (hooks -> side-stream all-reduces) +
+    GradScaler + fused Adam captured as ONE graph; replays must track an eager DDP-free twin bit for bit."""
+    from hipseg.ddp import HipDDP
+    from models.losses import HybridLoss
+    from models.UNet import UNet
+
+    x, t = _data()
+    crit = HybridLoss()
+
+    def make():
+        torch.manual_seed(11)
+        m = UNet().cuda().train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=True)
+        return m, opt, torch.amp.GradScaler("cuda")
+
+    def train_step(net, opt, scaler):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda"):
+            loss = crit(net(x), t)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m0, o0, sc0 = make()
+        ref_losses = [float(train_step(m0, o0, sc0)) for _ in range(6)]
+        m1, o1, sc1 = make()
+        ddp = HipDDP(m1, force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
+        losses = [float(train_step(ddp, o1, sc1)) for _ in range(3)]  # eager warm-up steps 0..2
+        HipDDP.quiesce_before_capture()  # (RCCL watchdog vs. capture: see its docstring)
+        graph = torch.cuda.CUDAGraph()
+        n0 = ddp.stats["comm_stream_collectives"]
+        with torch.cuda.graph(graph, stream=s):
+            static_loss = train_step(ddp, o1, sc1)
+        assert ddp.stats["comm_stream_collectives"] - n0 == len(ddp.buckets)  # captured, not skipped
+        # capture only records; replays are steps 3, 4, 5
+        for _ in range(3):
+            graph.replay()
+            losses.append(float(static_loss))
+        torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(s)
+    assert losses == ref_losses, (losses, ref_losses)
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        assert torch.equal(a, b)
+
+
+def case_unused_parameters_are_zero_filled_not_stale(pg):
+    """ClipUnet's bottleneck ConvBlock receives no gradient (its output is replaced by the fusion,
+    models/CLIP_models.py:126): the partially filled bucket must reduce zeros in those slots and leave .grad None."""
+    import torch.nn as nn
+
+    from hipseg.ddp import HipDDP
+    from models.CLIP_models import ClipUnet
+    from models.losses import HybridLoss
+
+    class Feats(nn.Module):
+        def forward(self, X):
+            return torch.linspace(-1, 1, X.shape[0] * 512, device=X.device).view(X.shape[0], 512)
+
+    torch.manual_seed(2)
+    model = ClipUnet(clip_feature_extractor=Feats()).cuda().train()
+    model.run_dead_bottleneck = False
+    crit = HybridLoss()
+    x, t = _data(2, 32)
+    _step(model, crit, x, t)
+    ref = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    assert ref["bottleneck.conv.0.weight"] is None
+    model.zero_grad(set_to_none=True)
+    for overlap in (True, False):
+        ddp = HipDDP(model, overlap=overlap, force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
+        for b in ddp.buckets:
+            b.flat.fill_(7.0)  # stale garbage
+        ddp.zero_grad(set_to_none=True)
+        _step(ddp, crit, x, t)
+        if not overlap:
+            ddp.reduce_gradients()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if ref[n] is None:
+                assert p.grad is None, n
+                bi, pi = ddp._where[p]
+                bucket = ddp.buckets[bi]
+                if any(q.grad is not None for q in bucket.params):  # (a wholly unused bucket is simply not reduced)
+                    assert float(bucket.views[pi].abs().max()) == 0.0, n
+            else:
+                assert torch.equal(p.grad, ref[n]), n
+        if overlap:
+            assert ddp.stats["zero_filled_slots"] > 0
+        ddp.remove_hooks()
+        model.zero_grad(set_to_none=True)
+
+
+CASES = {f.__name__[len("case_"):]: f for f in (case_hook_path_matches_plain_backward_bitwise,
+                                                case_overlapped_allreduce_captured_in_one_hipgraph,
+                                                case_unused_parameters_are_zero_filled_not_stale)}
+
+
+if __name__ == "__main__":
+    import torch.distributed as dist
+
+    name = sys.argv[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="env://", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        CASES[name](dist)
+    except BaseException:  # print at once: the watchdog may abort the process before a normal unwind finishes
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    print("CASE_OK", name, flush=True)
+    dist.destroy_process_group()

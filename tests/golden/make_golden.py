@@ -319,6 +319,26 @@ def gen_round2():
     with torch.no_grad():
         out["trained/train_logits"] = npy(m(xte))
     m.load_state_dict(saved)
+    # (2b) ClipUnet: the reference runs its (output-discarded) bottleneck ConvBlock, so one train-mode forward moves the
+    # bottleneck's BatchNorm buffers -- checkpoint state the drop-in must reproduce
+    feats = T("clip.feats", (2, 512), -1.0, 1.0)
+
+    class FakeExtractor(nn.Module):
+        def __init__(self, train=False):
+            super().__init__()
+
+        def forward(self, x):
+            return feats
+
+    ref_clip.ClipFeatureExtractor = FakeExtractor
+    cm = ref_clip.ClipUnet()
+    fill.fill_state_dict(cm.state_dict())
+    cm.train()
+    with torch.no_grad():
+        cm(T("clip.x", (2, 3, 32, 32)))
+    for k, v in cm.state_dict().items():
+        if k.startswith("bottleneck.") and k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            out[f"clip_bn/{k}"] = npy(v)
     np.savez_compressed(os.path.join(HERE, "models_r2.npz"), **out)
     print("models_r2.npz", len(out), "final loss", traj[-1], "median margin", float(out["trained/median_margin"]),
           "IoU vs target", float(out["trained/iou_vs_target"]))

@@ -288,3 +288,40 @@ def test_augment_contract_exact_and_statistical(M):
     tv = lambda z: float((z[..., 1:] - z[..., :-1]).abs().mean())
     nk = q[:, 0] == 0
     assert tv(o3.cpu()[nk]) < 0.8 * tv(x[nk])
+
+
+def test_clip_unet_dead_bottleneck_keeps_reference_checkpoint_state(M, golden):
+    """The reference's ClipUnet still RUNS its bottleneck ConvBlock although the fusion discards the result
+    (models/CLIP_models.py:125-126), so a train-mode forward moves bottleneck.conv.{1,4}.running_* and
+    num_batches_tracked.  The drop-in runs that block forward-only under no_grad (default) and must leave the same
+    buffers; with the switch off they stay untouched; gradients are unaffected either way."""
+    g = golden("models_r2")
+    feats = T("clip.feats", (2, 512), -1.0, 1.0).cuda()
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            return feats
+
+    x = T("clip.x", (2, 3, 32, 32)).cuda()
+    t = torch.from_numpy(fill.randint("clip.t", (2, 32, 32), 3)).cuda()
+    outs = {}
+    for flag in (True, False):
+        m = M.cm.ClipUnet(clip_feature_extractor=Fake())
+        fill.fill_state_dict(m.state_dict())
+        m = m.cuda().train()
+        m.run_dead_bottleneck = flag
+        before = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("bottleneck.")}
+        with M.hipseg.precision_mode("fp32"):
+            loss = M.ls.HybridLoss()(m(x), t)
+            loss.backward()
+        outs[flag] = (float(loss), m.out.weight.grad.clone())
+        sd = m.state_dict()
+        for k in before:
+            if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                continue
+            if flag:
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"clip_bn/{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+            else:
+                assert torch.equal(sd[k], before[k]), k
+        assert m.bottleneck.conv[0].weight.grad is None
+    assert outs[True][0] == outs[False][0] and torch.equal(outs[True][1], outs[False][1])
