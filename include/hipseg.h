@@ -16,6 +16,13 @@
  *   - every function only enqueues work on `stream` (no allocation, no sync: safe
  *     under hipGraph capture) and returns 0 on success or a negative HIPSEG_E* code;
  *     hipseg_last_error() gives the message for the calling thread.
+ *   - NOT exported, on purpose: the data-parallel gradient all-reduce (SURVEY 8b lists a possible
+ *     `bucket_allreduce(ptr, count, dtype, comm, stream)`).  The host of this path is Python on
+ *     PyTorch-ROCm, which owns the RCCL communicator (torch.distributed, backend "nccl"); wrapping
+ *     ncclAllReduce behind a second C entry point would only duplicate that plumbing.  The bucket
+ *     logic lives in image-segmentation_amd/hipseg/ddp.py (HipDDP, replacing
+ *     scripts/train_distributed.py:35); the kernels of this library write parameter gradients
+ *     straight into its flat fp32 buckets.
  */
 #ifndef HIPSEG_H
 #define HIPSEG_H

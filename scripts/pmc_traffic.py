@@ -2,11 +2,17 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, each with --kernel-trace only)
 into per-kernel HBM traffic per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950:
 FETCH_SIZE (KB) counts 128-B requests at 64 B for 16-B-per-lane streaming reads -> x2; WRITE_SIZE (KB) is exact.
+The output records the sha256 of the kernel sources it was measured on (bench.py reports `traffic: null` when they no
+longer match the sources of the run).
 usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -23,7 +29,8 @@ def per_kernel(path, counter):
 fetch, fc = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, wc = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"note": "bench.py --loop eager --steps 2 --warmup 1 under rocprofv3 --pmc <counter> --kernel-trace; bytes per "
-               "launch = counter(KB) * 1024 (* 2 for FETCH_SIZE on gfx950) / dispatches", "kernels": {}}
+               "launch = counter(KB) * 1024 (* 2 for FETCH_SIZE on gfx950) / dispatches",
+       "kernel_source_sha16": kernel_source_hash(), "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k]):
     rd = fetch[k] * 1024 * 2 / fc[k]
     wr = write.get(k, 0.0) * 1024 / max(wc.get(k, 0), 1)
