@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x * 4 + cl;
     double S = 0.0, Q = 0.0;
     if (c < C) {
-#pragma unroll 4
+#pragma unroll 8
         for (int t = sl; t < mtiles; t += 64) {
             S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
             Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < RC) {
-#pragma unroll 4
+        // 16 independent loads per round (same summation order): the loop is a chain of L2 round trips otherwise
+#pragma unroll 16
         for (int b = sl; b < nblk; b += 16) s += partial[(size_t)b * RC + c];
     }
     sm[sl][cl] = s;

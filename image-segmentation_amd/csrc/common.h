@@ -98,6 +98,7 @@ static __global__ __launch_bounds__(256) void colreduce_inplace_kernel(float* __
     if (r1 > rows) r1 = rows;
     double s = 0.0;
     if (c < RC)
+#pragma unroll 8
         for (int r = r0 + sl; r < r1; r += 4) s += (double)part[(size_t)r * RC + c];
     sm[sl][cl] = s;
     __syncthreads();

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restr
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < S; ++s) {  // (unrolling over s measured 2x SLOWER: 36 strided streams per lane thrash the TLB/L2)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] += src[s * sstride + t * tstride];
     }
