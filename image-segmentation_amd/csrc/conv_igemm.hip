@@ -1532,6 +1532,14 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
             // 128-wide tiles whose K splits into whole activation super-chunks inside one source tensor
             static const bool no_r64 = getenv("HIPSEG_NO_RING64") != nullptr;
             const bool tall = mode == HIPSEG_CONV3 && !no_tall && H >= 32 && bn >= 64 && tall_wgs >= (bn == 128 ? 256 : 512);
+            // a 128-wide tiling that leaves half the CUs without a workgroup (256 channels at 32x32: 128 workgroups on 256
+            // CUs): 64-wide tiles double the grid -- dec1.c0 59 -> 46 us, dec1.c1 and its data gradient 34 -> 28 us.  (With
+            // exactly one 128-wide workgroup per CU the 64-wide form measured SLOWER: bott.c1 70 -> 78 us.)
+            if (mode == HIPSEG_CONV3 && bn == 128 && (long)a.B * a.tiles_x * a.tiles_y * a.ntn * 2 <= a.ncu) {
+                ConvArgs b = a;
+                b.ntn = a.Np / 64;
+                return launch_dma<HIPSEG_CONV3, 64, 16>(b, s);
+            }
             if (mode == HIPSEG_CONV3 && bn == 128 && !no_r64 && !dbg && a.K == a.Kp) {
                 if (a.Kp % 32 == 0 && (C1 == 0 || C0 % 32 == 0))
                     return tall ? launch_ring64<32, 4>(a, s) : launch_ring64<16, 4>(a, s);
