@@ -557,35 +557,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     }
 }
 
-// 3x3 case: 16(u) x 16(v) x 9 tile per block.  Slab reads are 64-byte runs along v; the tile is turned in
-// LDS so the native (Cout=v, Cin=u, ky, kx) write is 576-byte runs (144 consecutive floats per v).
-__global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                             int S, int sstep, int CU, int CV, int CUp, int CVp) {
-    __shared__ float tile[16 * 145];  // 144 floats per v row + 1 pad: the transposing writes spread over 16 banks
-    const int tid = threadIdx.x;
-    const int u = tid >> 4, v = tid & 15;
-    const int u0 = blockIdx.y * 16, v0 = blockIdx.x * 16;
-    const size_t tstride = (size_t)CUp * CVp, sstride = 9 * tstride * sstep;
-    const float* src = slabs + (size_t)(u0 + u) * CVp + v0 + v;  // padded: always in bounds
-    float acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (int s = 0; s < S; ++s) {  // (unrolling over s measured 2x SLOWER: 36 strided streams per lane thrash the TLB/L2)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] += src[s * sstride + t * tstride];
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) tile[v * 145 + u * 9 + t] = acc[t];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int idx = k * 256 + tid;
-        const int vv = idx / 144, rem = idx % 144;
-        const int uu = rem / 9, t = rem % 9;
-        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t] = tile[vv * 145 + rem];
-    }
-}
-
 // Slab reduction of the 3x3 weight gradient in ONE launch for any number of slabs: a block owns a 4(u) x 32(v) x 9 tile
 // and splits the S slabs over NS = 2 / 4 / 8 slices of 128 lanes (up to 1024 threads: enough loads in flight -- the
 // reduction is a chain of L2/HBM round trips otherwise); slice partials meet in LDS and are summed in slice order, then
@@ -740,11 +711,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
         else
             rc = pl.NT == 9 ? launch<float, 9>(a, s) : launch<float, 1>(a, s);
         if (rc) return rc;
-        // many splits of a small weight tensor: pre-reduce chunks of 16 slabs in place (wide grid), then
-        // the (transposing) final pass walks the chunk heads only
         int S = pl.S, sstep = 1;
-        static const bool two_stage = getenv("HIPSEG_WGRAD_REDUCE2") != nullptr;  // A/B switch: the former two launches
-        if (mode == HIPSEG_CONV3 && !two_stage) {
+        if (mode == HIPSEG_CONV3) {  // one launch for any number of slabs
             const dim3 rg(cdiv(CV, 32), cdiv(CU, 4));  // (CVp, CUp are multiples of 32)
             if (pl.S >= 8)
                 hipLaunchKernelGGL(wgrad_reduce3_wide_kernel<8>, rg, dim3(1024), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp, pl.CVp);
@@ -755,6 +723,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
             HS_LAUNCH_CHECK("wgrad_reduce(wide)");
             continue;
         }
+        // 1x1 / ConvT: many splits of a small weight tensor are pre-reduced in chunks of 16 slabs in place (wide grid),
+        // then the (transposing) final pass walks the chunk heads only
         if (pl.S >= 32) {
             sstep = 16;
             S = cdiv(pl.S, sstep);
@@ -763,12 +733,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
                                sstep);
             HS_LAUNCH_CHECK("wgrad_prereduce");
         }
-        if (mode == HIPSEG_CONV3)
-            hipLaunchKernelGGL(wgrad_reduce3_kernel, dim3(cdiv(CV, 16), cdiv(CU, 16)), dim3(256), 0, s, slabs, dw, S,
-                               sstep, CU, CV, pl.CUp, pl.CVp);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slabs, dw, S, sstep, pl.NT, CU, CV,
-                               pl.CUp, pl.CVp, mode, ab);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slabs, dw, S, sstep, pl.NT, CU, CV, pl.CUp,
+                           pl.CVp, mode, ab);
         HS_LAUNCH_CHECK("wgrad_reduce");
     }
     return HIPSEG_OK;
