@@ -158,32 +158,23 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
             }
         }
     }
-    const int R = 2048 / Cout;
+    // block reduction over the pixel lanes, one accumulator row (input channel / bias) at a time: red[pl][Cout], then
+    // COLUMN-parallel sums -- thread c adds column c over the PL rows in row order (conflict-free consecutive reads;
+    // the former loop had the CG lanes of pl == 0 walk all rows alone: ~6 us of tail per block)
 #pragma unroll
     for (int r = 0; r <= MAXCIN; ++r) {
         if (r < Cin || r == MAXCIN) {
-            float t[V];
+            __syncthreads();
+            if (pl < PL) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) t[e] = 0.f;
-            for (int base = 0; base < PL; base += R) {
-                __syncthreads();
-                if (pl >= base && pl < base + R && pl < PL) {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) red[(pl - base) * Cout + cg * V + e] = acc[r][e];
-                }
-                __syncthreads();
-                if (pl == 0) {
-                    const int lim = (PL - base) < R ? (PL - base) : R;
-                    for (int j = 0; j < lim; ++j)
-#pragma unroll
-                        for (int e = 0; e < V; ++e) t[e] += red[j * Cout + cg * V + e];
-                }
+                for (int e = 0; e < V; ++e) red[pl * Cout + cg * V + e] = acc[r][e];
             }
-            if (pl == 0) {
-                const int row = r == MAXCIN ? Cin : r;
-#pragma unroll
-                for (int e = 0; e < V; ++e)
-                    partial[((size_t)blockIdx.x * (Cin + 1) + row) * Cout + cg * V + e] = t[e];
+            __syncthreads();
+            const int row = r == MAXCIN ? Cin : r;
+            for (int c = tid; c < Cout; c += 256) {
+                float t = 0.f;
+                for (int j = 0; j < PL; ++j) t += red[j * Cout + c];
+                partial[((size_t)blockIdx.x * (Cin + 1) + row) * Cout + c] = t;
             }
         }
     }
@@ -243,7 +234,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                                                         const float* __restrict__ w, T* __restrict__ dx,
                                                         float* __restrict__ partial, int B, long HW, int Cin, int Cout,
                                                         int CG, int PL, long ppb) {
-    __shared__ float red[2048];
+    __shared__ float red[2048 + 256];  // PL rows of (Cin + 1): PL * Cin <= 2048, PL <= 256
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
     float aw[MAXHC][V], ab[MAXHC];
@@ -308,35 +299,23 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
             }
         }
     }
-    const int R = 2048 / (Cin + 1);
+    // block reduction over the pixel lanes, one output channel at a time: red[pl][Cin + 1] (last column = bias sum), then
+    // column-parallel sums in row order (see stem_bwd_kernel)
 #pragma unroll
     for (int co = 0; co < MAXHC; ++co) {
         if (co < Cout) {
-            float t[V], tb = 0.f;
+            __syncthreads();
+            if (pl < PL) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) t[e] = 0.f;
-            for (int base = 0; base < PL; base += R) {
-                __syncthreads();
-                if (pl >= base && pl < base + R && pl < PL) {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) red[(pl - base) * (Cin + 1) + cg * V + e] = aw[co][e];
-                    if (cg == 0) red[(pl - base) * (Cin + 1) + Cin] = ab[co];
-                }
-                __syncthreads();
-                if (pl == 0) {
-                    const int lim = (PL - base) < R ? (PL - base) : R;
-                    for (int j = 0; j < lim; ++j) {
-#pragma unroll
-                        for (int e = 0; e < V; ++e) t[e] += red[j * (Cin + 1) + cg * V + e];
-                        if (cg == 0) tb += red[j * (Cin + 1) + Cin];
-                    }
-                }
+                for (int e = 0; e < V; ++e) red[pl * (Cin + 1) + cg * V + e] = aw[co][e];
+                if (cg == 0) red[pl * (Cin + 1) + Cin] = ab[co];
             }
-            if (pl == 0) {
-                float* dst = partial + ((size_t)blockIdx.x * Cout + co) * (Cin + 1);
-#pragma unroll
-                for (int e = 0; e < V; ++e) dst[cg * V + e] = t[e];
-                if (cg == 0) dst[Cin] = tb;
+            __syncthreads();
+            float* dst = partial + ((size_t)blockIdx.x * Cout + co) * (Cin + 1);
+            for (int c = tid; c <= Cin; c += 256) {
+                float t = 0.f;
+                for (int j = 0; j < PL; ++j) t += red[j * (Cin + 1) + c];
+                dst[c] = t;
             }
         }
     }
@@ -572,7 +551,7 @@ extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const f
 
 extern "C" int hipseg_head_bwd_blocks(int B, int H, int W) {
     long nb = ((long)B * H * W + 255) / 256;
-    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));  // (1024 measured slower: the per-block LDS tail dominates)
+    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
 }
 
 extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, const float* w, void* dx,
