@@ -185,7 +185,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
-        ctl = dist.new_group(backend="gloo")  # host-side agreement between ranks (never on the data path)
+        try:
+            ctl = dist.new_group(backend="gloo")  # host-side agreement between ranks (never on the data path)
+        except Exception as e:  # noqa: BLE001  (no usable host interface: every rank then decides for itself)
+            print(f"[rank {rank}] no gloo control group ({e!r})", file=sys.stderr, flush=True)
+            ctl = None
 
     import hipseg
     from hipseg import ops
