@@ -144,6 +144,46 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
     const PackDesc d = descs[blockIdx.y];
     const float* __restrict__ w = d.w;
     const int ks = d.ks, Cout = d.Cout, Cin = d.Cin, kk = ks * ks;
+    if constexpr (G == 8) {
+        // 3x3 weights with unpadded operands (every conv of the U-Nets): LDS-staged tile transposer.  The gathered path
+        // below reads each fp32 element with its own 4-byte load at a 36-byte (or Cin*36-byte) stride -- one 64-byte
+        // sector per element, ~1 GB of L2 sector traffic for 31 MB of weights.  Here a block reads 8 output-channel rows
+        // x KT input channels x 9 taps as 8 contiguous runs, and both operands are cut out of the LDS copy: forward
+        // wp[tap][k/8][n][8 k] and data-gradient wpt[8 - tap][n/8][k][8 n]; LDS rows of 577 floats keep both read
+        // patterns (stride 9 across k, stride 577 across n) bank-conflict-free.
+        if (d.kind == 0 && ks == 3 && Cin % 32 == 0 && Cout % 8 == 0 && d.Kp0 == Cin && d.Kp1 == Cout && d.Np0 == Cout &&
+            d.Np1 == Cin) {
+            __shared__ float tile[8][64 * 9 + 1];
+            const int KT = Cin % 64 == 0 ? 64 : 32, nkt = Cin / KT, ntl = nkt * (Cout / 8), row = KT * 9;
+            typedef T vec8 __attribute__((ext_vector_type(8)));
+            for (int tl = blockIdx.x; tl < ntl; tl += gridDim.x) {
+                const int kt = tl % nkt, ng = tl / nkt, n0 = ng * 8, k0 = kt * KT;
+                for (int i = threadIdx.x; i < 8 * row; i += 256) {
+                    const int r = i / row, c = i - r * row;
+                    tile[r][c] = w[((size_t)(n0 + r) * Cin + k0) * 9 + c];
+                }
+                __syncthreads();
+                for (int i = threadIdx.x; i < 9 * KT; i += 256) {  // forward: (tap, k-octet, n)
+                    const int n = i & 7, kgl = (i >> 3) % (KT / 8), t = i / KT;
+                    vec8 o;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) o[g] = (T)tile[n][(kgl * 8 + g) * 9 + t];
+                    T* dst = reinterpret_cast<T*>(d.wp) + (((size_t)t * (Cin / 8) + k0 / 8 + kgl) * d.Np0 + n0 + n) * 8;
+                    *reinterpret_cast<vec8*>(dst) = o;
+                }
+                for (int i = threadIdx.x; i < 9 * KT; i += 256) {  // data gradient: (tap, k), taps flipped
+                    const int k = i % KT, t = i / KT;
+                    vec8 o;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) o[g] = (T)tile[g][k * 9 + t];
+                    T* dst = reinterpret_cast<T*>(d.wpt) + (((size_t)(8 - t) * (Cout / 8) + ng) * d.Np1 + k0 + k) * 8;
+                    *reinterpret_cast<vec8*>(dst) = o;
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
     const int nv0 = (int)(d.total0 / G), nv1 = (int)(d.total1 / G);
     const int stride = gridDim.x * blockDim.x;
     typedef T vecT __attribute__((ext_vector_type(G)));

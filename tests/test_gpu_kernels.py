@@ -332,7 +332,10 @@ def test_pack_batch_matches_per_layer_pack(hs, prec, td, dt):
     L, ops = hs.L, hs.ops
     net = torch.nn.Sequential(torch.nn.Conv2d(24, 40, 3, padding=1), torch.nn.ConvTranspose2d(64, 32, 2, stride=2),
                               torch.nn.Conv2d(64, 64, 3, padding=1), torch.nn.Conv2d(3, 32, 1),
-                              torch.nn.ConvTranspose2d(12, 6, 2, stride=2)).cuda()
+                              torch.nn.ConvTranspose2d(12, 6, 2, stride=2),
+                              # unpadded 3x3 shapes: the LDS-staged tile path of the batch kernel (32- and 64-wide k tiles)
+                              torch.nn.Conv2d(32, 64, 3, padding=1), torch.nn.Conv2d(128, 256, 3, padding=1),
+                              torch.nn.Conv2d(256, 128, 3, padding=1)).cuda()
     ops._PACKED.clear()
     want = []
     for m in net:
@@ -343,7 +346,7 @@ def test_pack_batch_matches_per_layer_pack(hs, prec, td, dt):
     ops.prepack(net, prec)
     torch.cuda.synchronize()
     got = [ops._cached_pack(m.weight, dt) for m in net if not (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1))]
-    assert len(got) == len(want) == 4 and all(g is not None for g in got)
+    assert len(got) == len(want) == 7 and all(g is not None for g in got)
     for (gp, gt), (wp, wt) in zip(got, want):
         assert torch.equal(gp.float(), wp.float()) and torch.equal(gt.float(), wt.float())
     # a weight modified in place after prepack is no longer served from the cache
