@@ -34,6 +34,9 @@ inline unsigned grid_for(long total, int cap = 4096) {
 }
 
 constexpr int MAXCIN = 4;  // stem: RGB(A) images
+#ifndef STEM_FWD_BLOCKS
+#define STEM_FWD_BLOCKS 1024  // the per-thread weight prologue (40 loads) wants >= 16 items per thread behind it
+#endif
 
 // ------------------------------------------------------------------ stem: NCHW fp32 image -> NHWC
 template <typename T, int V>
@@ -494,7 +497,7 @@ extern "C" int hipseg_stem_fwd(int dtype, const float* x, const float* w, const 
     HS_REQUIRE((long)B * HW * (Cout / V) < (1l << 31), "stem_fwd: more than 2^31 (pixel, channel-vector) items");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
-        hipLaunchKernelGGL((stem_fwd_kernel<T_, V_>), dim3(grid_for(B * HW * (Cout / V_))), dim3(256), 0, s, x, w, b,
+        hipLaunchKernelGGL((stem_fwd_kernel<T_, V_>), dim3(grid_for(B * HW * (Cout / V_), STEM_FWD_BLOCKS)), dim3(256), 0, s, x, w, b,
                            (T_*)y, B, Cin, HW, Cout);
     });
     HS_LAUNCH_CHECK("stem_fwd");
