@@ -230,4 +230,4 @@ class OracleTrainer:
         loss = hybrid_loss(unet_forward(x, self.sd, self.arch, True, clip_features), target)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())
