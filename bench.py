@@ -46,12 +46,16 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet"])
-    ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "graph"),
-                    choices=["eager", "graph", "splitgraph"],
-                    help="graph: the whole step is ONE hipGraph replay; for N > 1 the bucketed RCCL all-reduces are "
-                         "captured inside it as side-stream branches overlapped with backward.  eager: Python "
-                         "launches every kernel each step (all-reduce overlapped from autograd hooks).  splitgraph "
-                         "(N > 1 only): hipGraph(fwd+bwd+pack) -> eager all-reduce (NOT overlapped) -> hipGraph(optimizer)")
+    ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "auto"),
+                    choices=["auto", "eager", "graph", "splitgraph"],
+                    help="auto: graph for one GPU, eager for N > 1 (measured on one MI355X the two run at the same "
+                         "rate -- 4.494 vs 4.498 ms/step plain, 4.82 vs 4.76 with the 1-rank DDP rehearsal: the step is "
+                         "GPU-bound -- so N > 1 takes the form that needs no RCCL-inside-hipGraph capture, which a "
+                         "1-GPU development box cannot exercise with real peers).  graph: the whole step is ONE "
+                         "hipGraph replay; for N > 1 the bucketed RCCL all-reduces are captured inside it as side-stream "
+                         "branches overlapped with backward.  eager: Python launches every kernel each step (all-reduce "
+                         "overlapped from autograd hooks on a side stream).  splitgraph (N > 1 only): hipGraph(fwd+bwd+"
+                         "pack) -> eager all-reduce (NOT overlapped) -> hipGraph(optimizer)")
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
                     help="hip: hipseg.optim.Adam (one HIP launch per step); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,6 +211,8 @@ def main():
     else:
         model = getattr(un, args.model)().to(dev).train()
     loop = args.loop
+    if loop == "auto":
+        loop = "eager" if world > 1 else "graph"
     if loop == "splitgraph" and not ddp:
         loop = "graph"
     use_graph = loop in ("graph", "splitgraph")
