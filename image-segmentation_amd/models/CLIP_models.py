@@ -2,9 +2,11 @@
 import torch
 import torch.nn as nn
 
+from models.processing_blocks import *  # noqa: F401,F403  (as the reference module does, CLIP_models.py:4)
 from models.processing_blocks import (ClipFeatureExtractor, ConvBlock, ConvBlockDownsample,  # noqa: F401
-                                      ConvBlockUpsampleSkip, CrossAttentionFusion)
-from models.UNet import UNet
+                                      ConvBlockUpsample, ConvBlockUpsampleSkip, CrossAttentionFusion,
+                                      ResNet34FeatureExtractor)
+from models.UNet import UNet, _head, _stem
 
 
 
@@ -45,3 +47,55 @@ class ClipUnet(UNet):
             return self.cross_attention_fusion(ref, clip_features)
 
         return self._trunk(X, fuse=fuse)
+
+
+class ClipAutoencoder(nn.Module):
+    """CLIP vector -> Linear(512, 64*16*16) -> three ConvBlockUpsample -> ConvBlockUpsampleSkip with the 1x1-stem image
+    features -> 1x1 head (reference: CLIP_models.py:136-188; `activation` is stored but not applied there).  Same
+    blocks, same kernels as the U-Nets; the coupler is a plain torch Linear."""
+
+    def __init__(self, out_channels=3, in_channels=3, activation=nn.Identity(), clip_feature_extractor=None):
+        super().__init__()
+        self.clip_feature_extractor = (clip_feature_extractor if clip_feature_extractor is not None
+                                       else ClipFeatureExtractor(train=False))
+        self.input = nn.Conv2d(in_channels, 32, kernel_size=1, padding=0)
+        self.coupler = nn.Linear(512, 16384)
+        self.dec1 = ConvBlockUpsample(64, 64)
+        self.dec2 = ConvBlockUpsample(64, 64)
+        self.dec3 = ConvBlockUpsample(64, 32)
+        self.dec4 = ConvBlockUpsampleSkip(32, 32)
+        self.out = nn.Conv2d(32, out_channels, kernel_size=1, padding=0)
+        self.activation = activation
+
+    @torch.compiler.disable
+    def forward(self, X):
+        clip_features = self.clip_feature_extractor(X)
+        inp = _stem(self.input, X)
+        bottleneck = self.coupler(clip_features.float()).view(-1, 64, 16, 16)
+        d = self.dec3(self.dec2(self.dec1(bottleneck)))
+        return _head(self.out, self.dec4(d, inp))
+
+
+class ClipResSegmentationModel(nn.Module):
+    """ResNet-34 features fused with the CLIP vector, five ConvBlockUpsample, ConvBlock on cat([dec5, X]) (reference:
+    CLIP_models.py:8-61).  Needs torchvision's pretrained ResNet-34 (ResNet34FeatureExtractor raises ImportError
+    without it); the decoder runs on the HIP blocks."""
+
+    def __init__(self, out_channels=3, in_channels=3, activation=nn.Identity()):
+        super().__init__()
+        self.clip_feature_extractor = ClipFeatureExtractor(train=False)
+        self.encoder = ResNet34FeatureExtractor(train=False)
+        self.cross_attention_fusion = CrossAttentionFusion(512, num_heads=4)
+        self.dec1 = ConvBlockUpsample(512, 256)
+        self.dec2 = ConvBlockUpsample(256, 128)
+        self.dec3 = ConvBlockUpsample(128, 64)
+        self.dec4 = ConvBlockUpsample(64, 32)
+        self.dec5 = ConvBlockUpsample(32, 16)
+        self.out = ConvBlock(in_channels=19, out_channels=out_channels)
+
+    @torch.compiler.disable
+    def forward(self, X):
+        clip_features = self.clip_feature_extractor(X)
+        attn = self.cross_attention_fusion(self.encoder(X), clip_features)
+        d = self.dec5(self.dec4(self.dec3(self.dec2(self.dec1(attn)))))
+        return self.out(torch.cat([d.float(), X.float()], dim=1)).float()

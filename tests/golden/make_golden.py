@@ -339,6 +339,24 @@ def gen_round2():
     for k, v in cm.state_dict().items():
         if k.startswith("bottleneck.") and k.endswith(("running_mean", "running_var", "num_batches_tracked")):
             out[f"clip_bn/{k}"] = npy(v)
+    # (2c) ClipAutoencoder (models/CLIP_models.py:136-188): Linear coupler -> ConvBlockUpsample x3 -> ConvBlockUpsampleSkip
+    ca = ref_clip.ClipAutoencoder()
+    fill.fill_state_dict(ca.state_dict())
+    xa = T("clipae.x", (2, 3, 32, 32))
+    ta = torch.from_numpy(fill.randint("clipae.t", (2, 32, 32), 3))
+    ca.eval()
+    with torch.no_grad():
+        out["clipae/eval_logits"] = npy(ca(xa))
+    ca.train()
+    lga = ca(xa)
+    la = HybridLoss()(lga, ta)
+    la.backward()
+    out["clipae/train_logits"] = npy(lga)
+    out["clipae/ce_loss"] = npy(la)
+    for k in ("coupler.weight", "dec1.up.weight", "dec4.conv.conv.3.weight", "out.weight", "input.weight"):
+        g_ = dict(ca.named_parameters())[k].grad
+        out[f"clipae/gradstat/{k}"] = np.array([float(g_.double().sum()), float(g_.double().abs().sum()),
+                                                float(g_.double().pow(2).sum())])
     np.savez_compressed(os.path.join(HERE, "models_r2.npz"), **out)
     print("models_r2.npz", len(out), "final loss", traj[-1], "median margin", float(out["trained/median_margin"]),
           "IoU vs target", float(out["trained/iou_vs_target"]))

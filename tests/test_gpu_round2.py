@@ -325,3 +325,39 @@ def test_clip_unet_dead_bottleneck_keeps_reference_checkpoint_state(M, golden):
                 assert torch.equal(sd[k], before[k]), k
         assert m.bottleneck.conv[0].weight.grad is None
     assert outs[True][0] == outs[False][0] and torch.equal(outs[True][1], outs[False][1])
+
+
+def test_clip_autoencoder_fp32_vs_reference_golden(M, golden):
+    """ClipAutoencoder (models/CLIP_models.py:136-188; same blocks, ConvBlockUpsample chain + one skip block whose
+    256x256 up-sample is bilinearly resized down to the 32x32 skip): fp32 logits within 1e-4 of the reference."""
+    g = golden("models_r2")
+    feats = T("clip.feats", (2, 512), -1.0, 1.0).cuda()
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            return feats
+
+    m = M.cm.ClipAutoencoder(clip_feature_extractor=Fake())
+    fill.fill_state_dict(m.state_dict())
+    m = m.cuda()
+    x = T("clipae.x", (2, 3, 32, 32)).cuda()
+    t = torch.from_numpy(fill.randint("clipae.t", (2, 32, 32), 3)).cuda()
+    with M.hipseg.precision_mode("fp32"):
+        m.eval()
+        with torch.no_grad():
+            ev = m(x)
+        m.train()
+        logits = m(x)
+        loss = M.ls.HybridLoss()(logits, t)
+        loss.backward()
+    assert np.abs(ev.cpu().numpy() - g["clipae/eval_logits"]).max() <= 1e-4
+    assert np.abs(logits.detach().cpu().numpy() - g["clipae/train_logits"]).max() <= 1e-4
+    assert abs(float(loss) - float(g["clipae/ce_loss"])) <= 1e-5
+    params = dict(m.named_parameters())
+    for k in ("coupler.weight", "dec1.up.weight", "dec4.conv.conv.3.weight", "out.weight", "input.weight"):
+        gd = params[k].grad.double()
+        np.testing.assert_allclose([float(gd.abs().sum()), float(gd.pow(2).sum())], g[f"clipae/gradstat/{k}"][1:], rtol=5e-3,
+                                   atol=1e-6, err_msg=k)
+    with torch.autocast("cuda"), torch.no_grad():
+        tb = m(x).float().cpu().numpy()
+    assert np.isfinite(tb).all()
