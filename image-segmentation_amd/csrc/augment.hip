@@ -228,9 +228,42 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const float* __restr
     }
 }
 
+// parameter table from 8 uniforms per sample (one tiny launch instead of ~20 elementwise host ops)
+__global__ void augment_params_kernel(const float* __restrict__ u, float* __restrict__ params, int B, int keep_stride,
+                                      float flip_p, float rotate_p, float degrees, float brightness, float contrast,
+                                      float saturation, float hue, float sigma_lo, float sigma_hi) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* r = u + (size_t)b * 8;
+    float* p = params + (size_t)b * NP;
+    const float theta = (r[1] < rotate_p) ? (r[2] * 2.0f - 1.0f) * degrees * 0.017453292519943295f : 0.0f;
+    p[0] = (b % keep_stride == 0) ? 1.0f : 0.0f;
+    p[1] = r[0] < flip_p ? 1.0f : 0.0f;
+    p[2] = cosf(theta);
+    p[3] = sinf(theta);
+    p[4] = 1.0f + (r[3] * 2.0f - 1.0f) * brightness;
+    p[5] = 1.0f + (r[4] * 2.0f - 1.0f) * contrast;
+    p[6] = 1.0f + (r[5] * 2.0f - 1.0f) * saturation;
+    p[7] = (r[6] * 2.0f - 1.0f) * hue * 6.283185307179586f;
+    p[8] = sigma_lo + r[7] * (sigma_hi - sigma_lo);
+    for (int i = 9; i < NP; ++i) p[i] = 0.0f;
+}
+
 }  // namespace
 
 extern "C" size_t hipseg_augment_workspace_elems(int B) { return (size_t)(B > 0 ? B : 0) * NPART; }
+
+extern "C" int hipseg_augment_params(const float* uniforms, float* params, int B, int keep_stride, float flip_p,
+                                     float rotate_p, float degrees, float brightness, float contrast, float saturation,
+                                     float hue, float sigma_lo, float sigma_hi, hipseg_stream_t stream) {
+    HS_REQUIRE(uniforms && params && B > 0 && keep_stride >= 1, "augment_params: bad arguments");
+    HS_REQUIRE(sigma_lo > 0.f && sigma_hi >= sigma_lo, "augment_params: bad sigma range (%g, %g)", sigma_lo, sigma_hi);
+    hipLaunchKernelGGL(augment_params_kernel, dim3(cdiv(B, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), uniforms,
+                       params, B, keep_stride, flip_p, rotate_p, degrees, brightness, contrast, saturation, hue, sigma_lo,
+                       sigma_hi);
+    HS_LAUNCH_CHECK("augment_params");
+    return HIPSEG_OK;
+}
 
 extern "C" int hipseg_augment(const float* images, const int64_t* masks, const float* extra, int n_extra,
                               const float* params, const int* order, float* partial, float* out_images,

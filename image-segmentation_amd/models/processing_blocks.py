@@ -229,21 +229,16 @@ class _AugmentorBase(nn.Module):
         self.last_params = None  # (params, order) of the most recent call: lets tests replay it on the CPU oracle
 
     def sample_params(self, B, device):
-        """(B, AUG_NPARAM) fp32 table + int32[4] op order, sampled on `device` (see include/hipseg.h)."""
+        """(B, AUG_NPARAM) fp32 table + int32[4] op order, sampled on `device` (see include/hipseg.h): two torch RNG
+        launches (8 uniforms per sample, the op permutation) and one tiny kernel that derives the table."""
         from hipseg import _lib as L
 
+        ops._require_gpu(torch.empty(0, device=device))
         u = torch.rand(B, 8, device=device)
-        p = torch.zeros(B, L.AUG_NPARAM, device=device)
-        idx = torch.arange(B, device=device)
-        p[:, 0] = (idx % (self.augmentations_per_datapoint + 1) == 0).float()
-        p[:, 1] = (u[:, 0] < self.flip_p).float()
-        theta = torch.deg2rad((u[:, 2] * 2.0 - 1.0) * self.degrees) * (u[:, 1] < self.rotate_p).float()
-        p[:, 2], p[:, 3] = torch.cos(theta), torch.sin(theta)
-        p[:, 4] = 1.0 + (u[:, 3] * 2.0 - 1.0) * self.brightness
-        p[:, 5] = 1.0 + (u[:, 4] * 2.0 - 1.0) * self.contrast
-        p[:, 6] = 1.0 + (u[:, 5] * 2.0 - 1.0) * self.saturation
-        p[:, 7] = (u[:, 6] * 2.0 - 1.0) * self.hue * (2.0 * math.pi)
-        p[:, 8] = self.sigma[0] + u[:, 7] * (self.sigma[1] - self.sigma[0])
+        p = torch.empty(B, L.AUG_NPARAM, device=device)
+        L.augment_params(ops.ptr(u), ops.ptr(p), B, self.augmentations_per_datapoint + 1, self.flip_p, self.rotate_p,
+                         self.degrees, self.brightness, self.contrast, self.saturation, self.hue, self.sigma[0],
+                         self.sigma[1], ops._stream())
         order = torch.randperm(4, device=device).to(torch.int32)
         return p, order
 

@@ -262,6 +262,14 @@ int hipseg_adam_step(const void* host_descs, int ntensors, int* state, const flo
  * partial: fp32 workspace of hipseg_augment_workspace_elems(B).  Outputs must not alias inputs. */
 #define HIPSEG_AUG_NPARAM 16
 size_t hipseg_augment_workspace_elems(int B);
+/* params table from `uniforms` (B x 8 floats in [0,1)): [0] flip draw, [1] rotate draw, [2] angle, [3..6] brightness /
+ * contrast / saturation / hue, [7] sigma -- kornia's documented defaults are the caller's arguments
+ * (RandomHorizontalFlip p, RandomRotation p and degrees, ColorJitter ranges, RandomGaussianBlur sigma range);
+ * sample b is kept untouched when b % keep_stride == 0 (keep_stride = augmentations_per_datapoint + 1). */
+int hipseg_augment_params(const float* uniforms, float* params, int B, int keep_stride, float flip_p,
+                          float rotate_p, float degrees, float brightness, float contrast,
+                          float saturation, float hue, float sigma_lo, float sigma_hi,
+                          hipseg_stream_t stream);
 int hipseg_augment(const float* images, const int64_t* masks, const float* extra, int n_extra,
                    const float* params, const int* order, float* partial, float* out_images,
                    int64_t* out_masks, float* out_extra, int B, int H, int W, hipseg_stream_t stream);
