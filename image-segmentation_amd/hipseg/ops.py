@@ -10,6 +10,7 @@ import os
 import weakref
 
 import torch
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib as L
 
@@ -138,7 +139,9 @@ def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H,
 # ---- packed MFMA operands of the weights.  A model packs ALL its conv / ConvT weights with one launch at the start of
 # a forward (prepack); the per-layer helpers below first look the weight up in that cache (same storage, same
 # version counter) and only pack individually when it is not there (stand-alone block calls, tests).
-_PACKED = {}   # (data_ptr, shape, dt) -> (version, wp, wpt)
+# keyed by the weight tensor OBJECT (weakly): an entry dies with its parameter.  (Keyed by address, a freed model's entry
+# was served to a new tensor that the allocator placed at the same address with the same shape and version counter.)
+_PACKED = WeakTensorKeyDictionary()  # weight tensor (by identity) -> {dt: (version, data_ptr, wp, wpt)}
 _PLANS = weakref.WeakKeyDictionary()  # module -> {dt: _PackPlan}; dies with the module (no id() reuse aliasing)
 
 
@@ -193,13 +196,13 @@ def prepack(module, prec):
         plans[dt] = plan
     L.pack_batch(ptr(plan.desc), plan.n, dt, plan.max_total, _stream())
     for (w, _), (wp, wpt) in zip(plan.params, plan.bufs):
-        _PACKED[(w.data_ptr(), tuple(w.shape), dt)] = (w._version, wp, wpt)
+        _PACKED.setdefault(w, {})[dt] = (w._version, w.data_ptr(), wp, wpt)
 
 
 def _cached_pack(w, dt):
-    e = _PACKED.get((w.data_ptr(), tuple(w.shape), dt))
-    if e is not None and e[0] == w._version and e[1].device == w.device:
-        return e[1], e[2]
+    e = _PACKED.get(w, {}).get(dt)
+    if e is not None and e[0] == w._version and e[1] == w.data_ptr() and e[2].device == w.device:
+        return e[2], e[3]
     return None
 
 

@@ -2,6 +2,8 @@
 import torch
 import torch.nn as nn
 
+from hipseg import ops
+
 from models.processing_blocks import *  # noqa: F401,F403  (as the reference module does, CLIP_models.py:4)
 from models.processing_blocks import (ClipFeatureExtractor, ConvBlock, ConvBlockDownsample,  # noqa: F401
                                       ConvBlockUpsample, ConvBlockUpsampleSkip, CrossAttentionFusion,
@@ -70,6 +72,7 @@ class ClipAutoencoder(nn.Module):
     @torch.compiler.disable
     def forward(self, X):
         clip_features = self.clip_feature_extractor(X)
+        ops.prepack(self, ops.precision())  # all conv / ConvT operands of this step, one launch
         inp = _stem(self.input, X)
         bottleneck = self.coupler(clip_features.float()).view(-1, 64, 16, 16)
         d = self.dec3(self.dec2(self.dec1(bottleneck)))
@@ -96,6 +99,7 @@ class ClipResSegmentationModel(nn.Module):
     @torch.compiler.disable
     def forward(self, X):
         clip_features = self.clip_feature_extractor(X)
+        ops.prepack(self, ops.precision())
         attn = self.cross_attention_fusion(self.encoder(X), clip_features)
         d = self.dec5(self.dec4(self.dec3(self.dec2(self.dec1(attn)))))
         return self.out(torch.cat([d.float(), X.float()], dim=1)).float()
