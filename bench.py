@@ -107,8 +107,10 @@ def _config_index(args, world):
 # The file records the sha256 of the kernel sources it was measured on; a mismatch with the sources of THIS run means
 # the numbers are stale and `traffic` is reported as null.
 _PMC_FILE = "r02_pmc_traffic.json"
-_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": ("wgrad_dma_kernel<9,", "wgrad_reduce", "colreduce_inplace_kernel"),
-                "conv_igemm<bf16,CONV3,BN128>": ("conv_igemm_dma_kernel<0, 128,", "conv3_ring64_kernel")}
+# roofline key -> (kernels whose launches are counted, helper kernels whose bytes are added to them)
+_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": (("wgrad_dma_kernel<9,",), ("wgrad_reduce3_wide",)),
+                "conv_igemm<bf16,CONV3,BN128>": (("conv3_ring64_kernel", "conv_igemm_dma_kernel<0, 128,",
+                                                  "conv_igemm_dma_kernel<0, 64, 16>"), ())}
 _PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "bn.hip", "common.h")
 
 
@@ -128,9 +130,9 @@ def _pmc_traffic(key, args):
     if doc.get("kernel_source_sha16") != kernel_source_hash():
         return None, f"profiles/{_PMC_FILE} was measured on other kernel sources (stale): re-run scripts/pmc.sh"
     ks = doc["kernels"]
-    main_pat = _PMC_KERNELS[key][0]
-    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(p in k for p in _PMC_KERNELS[key]))
-    n = sum(v["launches"] for k, v in ks.items() if main_pat in k)
+    main, extra = _PMC_KERNELS[key]
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(p in k for p in main + extra))
+    n = sum(v["launches"] for k, v in ks.items() if any(p in k for p in main))
     return (round(tot / n), f"profiles/{_PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)") \
         if n else (None, "kernel not in the PMC pass")
 
