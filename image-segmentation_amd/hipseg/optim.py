@@ -52,15 +52,16 @@ class Adam(torch.optim.Optimizer):
                 v.copy_(s["exp_avg_sq"])
             s["exp_avg"], s["exp_avg_sq"] = m, v
             o += (p.numel() + 3) // 4 * 4
-        st = {"params": params, "flat": (flat_m, flat_v), "counter": torch.zeros(2, dtype=torch.int32, device=dev),
-              "tables": {}}
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        counter[0] = getattr(self, "_loaded_steps", {}).pop(gi, 0)  # (restored by load_state_dict)
+        st = {"params": params, "flat": (flat_m, flat_v), "counter": counter, "tables": {}}
         self._hip[gi] = st
         return st
 
     def _table(self, st, active):
         """host descriptor table for the parameters that have a gradient; cached per pointer set (the caching allocator
         hands back the same gradient addresses step after step).  Read by hipseg_adam_step during the call only."""
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in active)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in active)
         t = st["tables"].get(key)
         if t is not None:
             return t
@@ -100,6 +101,25 @@ class Adam(torch.optim.Optimizer):
                         float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                         _stream())
         return loss
+
+    # ------------------------------------------------------------------ checkpointing (torch.optim.Adam's layout)
+    def state_dict(self):
+        """torch.optim.Adam-compatible: per-parameter `step` (the group's device counter), `exp_avg`, `exp_avg_sq`."""
+        for gi, group in enumerate(self.param_groups):
+            n = self.step_count(gi)
+            for p in group["params"]:
+                if "exp_avg" in self.state.get(p, {}):
+                    self.state[p]["step"] = torch.tensor(float(n))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._hip = {}  # moments are re-homed into fresh flat buffers (and the counter restored) at the next step
+        self._loaded_steps = {}
+        for gi, group in enumerate(self.param_groups):
+            steps = [int(self.state[p]["step"]) for p in group["params"] if "step" in self.state.get(p, {})]
+            if steps:
+                self._loaded_steps[gi] = max(steps)
 
     def step_count(self, group=0):
         """number of applied (non-skipped) steps of a group (host sync)."""

@@ -425,3 +425,48 @@ def test_hip_adam_matches_torch_adam():
     assert opt.step_count() == applied + 1 + 3
     for p, rp in zip(dev_p, ref_p):
         np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=5e-5, atol=5e-6)
+
+
+def test_hip_adam_state_dict_roundtrip_with_torch_adam():
+    """hipseg.optim.Adam's state_dict has torch.optim.Adam's layout: a run continued from a checkpoint -- loaded into a
+    fresh hipseg Adam or into torch.optim.Adam -- follows the uninterrupted run."""
+    from hipseg.optim import Adam
+
+    torch.manual_seed(1)
+    shapes = [(64, 32, 3, 3), (17,), (3, 5)]
+    init = [torch.randn(s) for s in shapes]
+    grads = [[torch.randn(s) for s in shapes] for _ in range(6)]
+    kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+
+    def run(opt_cls, params, steps, opt=None):
+        opt = opt or opt_cls(params, **kw)
+        for gs in steps:
+            for p, g in zip(params, gs):
+                p.grad = g.to(p.device).clone()
+            opt.step()
+        return opt
+
+    full = [p.clone().cuda().requires_grad_(True) for p in init]
+    run(Adam, full, grads)
+    half = [p.clone().cuda().requires_grad_(True) for p in init]
+    o1 = run(Adam, half, grads[:3])
+    sd = o1.state_dict()
+    assert sorted(sd["state"][0]) == ["exp_avg", "exp_avg_sq", "step"] and float(sd["state"][0]["step"]) == 3.0
+    # (a) continue in a fresh hipseg Adam
+    cont = [p.detach().clone().requires_grad_(True) for p in half]
+    o2 = Adam(cont, **kw)
+    o2.load_state_dict(sd)
+    run(Adam, cont, grads[3:], opt=o2)
+    assert o2.step_count() == 6
+    for a, b in zip(cont, full):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # (b) continue in torch.optim.Adam on the CPU from the same checkpoint
+    cpu = [p.detach().cpu().clone().requires_grad_(True) for p in half]
+    o3 = torch.optim.Adam(cpu, **kw)
+    o3.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                        "param_groups": [{**g, **{k: torch.optim.Adam(cpu, **kw).param_groups[0][k]
+                                                  for k in torch.optim.Adam(cpu, **kw).param_groups[0] if k not in g}}
+                                         for g in sd["param_groups"]]})
+    run(torch.optim.Adam, cpu, grads[3:], opt=o3)
+    for a, b in zip(cpu, full):
+        np.testing.assert_allclose(a.detach().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
