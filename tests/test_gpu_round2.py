@@ -361,3 +361,48 @@ def test_clip_autoencoder_fp32_vs_reference_golden(M, golden):
     with torch.autocast("cuda"), torch.no_grad():
         tb = m(x).float().cpu().numpy()
     assert np.isfinite(tb).all()
+
+
+def test_reference_loop_body_end_to_end_learns(M):
+    """The reference's per-step loop body (models/model_wrappers.py:160-177) with every drop-in piece at once: on-device
+    DataAugmentor -> autocast forward -> HybridLoss -> GradScaler -> hipseg.optim.Adam (the `optimizer_class` hook),
+    on the learnable blob task.  The loss must fall and the validation IoU (IoU / PixelAccuracy / 2*IoU/(1+IoU), as
+    model_wrappers.py:209-211) must rise well above chance."""
+    from hipseg.optim import Adam
+    from models.processing_blocks import DataAugmentor
+
+    torch.manual_seed(0)
+    model = M.un.UNet().cuda()
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    crit, iou, acc = M.ls.HybridLoss(), M.ls.IoU(), M.ls.PixelAccuracy()
+    aug = DataAugmentor(4).cuda()
+    # colour jitter off: the task's label IS the brightest channel, hue / saturation changes would relabel it
+    aug.brightness = aug.contrast = aug.saturation = aug.hue = 0.0
+
+    def batch(seed, B=10):
+        g = torch.Generator().manual_seed(seed)
+        low = torch.rand(B, 3, 8, 8, generator=g)
+        x = torch.nn.functional.interpolate(low, size=(64, 64), mode="bilinear", align_corners=True)
+        return x.cuda(), x.argmax(1).cuda()
+
+    losses = []
+    model.train()
+    for step in range(60):
+        x, t = batch(step)
+        x, t = aug(x, t)  # (rotated-in corners: zero image, class 0 -- the augmentor's zero fill of both)
+        opt.zero_grad()
+        with torch.autocast("cuda"):
+            loss = crit(model(x), t)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+    assert opt.step_count() >= 55  # (GradScaler may skip a few early steps while it calibrates the scale)
+    model.eval()
+    xv, tv = batch(10_000)
+    with torch.no_grad(), torch.autocast("cuda"):
+        out = model(xv)
+        i, a = float(iou(out, tv)), float(acc(out, tv))
+    assert i > 0.5 and a > 0.6 and 2 * i / (1 + i) > 0.6, (i, a)
