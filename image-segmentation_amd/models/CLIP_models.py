@@ -11,18 +11,35 @@ from models.processing_blocks import (ClipFeatureExtractor, ConvBlock, ConvBlock
 from models.UNet import UNet, _head, _stem
 
 
+class _DeadBranchZeroGrads(torch.autograd.Function):
+    """identity on `y`; in backward every listed parameter receives an all-zero gradient (written straight into its
+    HipDDP bucket slot when it has one)."""
+
+    @staticmethod
+    def forward(ctx, y, *params):
+        ctx.params = params
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(ops.grad_out(p).zero_() for p in ctx.params)
+
 
 class ClipUnet(UNet):
     """UNet trunk whose bottleneck output is REPLACED by CrossAttentionFusion(bottleneck, clip)
     (reference: CLIP_models.py:115-134; `activation` is stored but never applied there).
-    Because the fusion output does not depend on the bottleneck features (degenerate attention),
-    the bottleneck ConvBlock contributes nothing to the output or to any gradient.  The reference
-    still runs it, which in train mode updates its BatchNorm running statistics and
-    `num_batches_tracked` -- state that ends up in checkpoints.  With `run_dead_bottleneck` (default
-    True) the block's FORWARD is therefore executed in train mode, under no_grad (nothing is saved,
-    nothing runs in backward, its parameters receive no gradient -- the reference's are exactly zero
-    up to rounding), so a saved state_dict matches the reference's; in eval mode it changes no state
-    and is skipped.  Set it to False to drop the ~4 % of step time it costs."""
+    Because the fusion output does not depend on the bottleneck features (degenerate attention:
+    every key is the same CLIP token, so the softmax is uniform whatever the query), the
+    bottleneck ConvBlock contributes nothing to the output, and its true gradient is zero.  The
+    reference still runs it, which has two visible effects on the state a checkpoint holds:
+      * in train mode its BatchNorm running statistics and `num_batches_tracked` move;
+      * its parameters receive a gradient tensor (zero up to ~1e-11 rounding residue of the softmax backward, measured
+        on the 224 x 224 golden), NOT None -- so Adam's `weight_decay` (1e-4 in the reference's loops,
+        model_wrappers.py:43) keeps acting on them and they shrink by ~lr per step.
+    With `run_dead_bottleneck` (default True) the block's FORWARD is therefore executed in train mode under no_grad
+    (nothing saved, nothing run in backward) and its parameters receive exact-zero gradients, so the optimizer treats
+    them as the reference's does; in eval mode it changes no state and is skipped.  Set it to False to drop the
+    ~4 % of step time it costs (the parameters then get no gradient at all)."""
 
     run_dead_bottleneck = True
 
@@ -46,7 +63,10 @@ class ClipUnet(UNet):
                     self.bottleneck(h)  # BatchNorm bookkeeping only (see the class docstring)
             B, _, H, W = h.shape
             ref = h.new_empty((B, 512, H, W), device="meta")
-            return self.cross_attention_fusion(ref, clip_features)
+            y = self.cross_attention_fusion(ref, clip_features)
+            if self.run_dead_bottleneck and self.bottleneck.training and torch.is_grad_enabled() and y.requires_grad:
+                y = _DeadBranchZeroGrads.apply(y, *[p for p in self.bottleneck.parameters() if p.requires_grad])
+            return y
 
         return self._trunk(X, fuse=fuse)
 

@@ -339,6 +339,23 @@ def gen_round2():
     for k, v in cm.state_dict().items():
         if k.startswith("bottleneck.") and k.endswith(("running_mean", "running_var", "num_batches_tracked")):
             out[f"clip_bn/{k}"] = npy(v)
+    # ... and its parameters get a gradient TENSOR (rounding residue of a mathematically zero gradient), so the
+    # reference's Adam(weight_decay=1e-4) (model_wrappers.py:43) keeps shrinking them: three of its loop-body steps in
+    # fp32, then a few rows of the dead and of the live weights
+    cm2 = ref_clip.ClipUnet()
+    fill.fill_state_dict(cm2.state_dict())
+    cm2.train()
+    opt2 = torch.optim.Adam(cm2.parameters(), lr=1e-3, weight_decay=1e-4)
+    xs, ts = T("clip.x", (2, 3, 32, 32)), torch.from_numpy(fill.randint("clip.t", (2, 32, 32), 3))
+    for _ in range(3):
+        opt2.zero_grad()
+        HybridLoss()(cm2(xs), ts).backward()
+        opt2.step()
+    sd2 = cm2.state_dict()
+    out["clip_adam3/bottleneck.conv.0.weight[:4]"] = npy(sd2["bottleneck.conv.0.weight"][:4])
+    out["clip_adam3/bottleneck.conv.4.weight"] = npy(sd2["bottleneck.conv.4.weight"])
+    out["clip_adam3/dec1.up.weight[:2]"] = npy(sd2["dec1.up.weight"][:2])
+    out["clip_adam3/out.weight"] = npy(sd2["out.weight"])
     # (2c) ClipAutoencoder (models/CLIP_models.py:136-188): Linear coupler -> ConvBlockUpsample x3 -> ConvBlockUpsampleSkip
     ca = ref_clip.ClipAutoencoder()
     fill.fill_state_dict(ca.state_dict())
@@ -357,6 +374,59 @@ def gen_round2():
         g_ = dict(ca.named_parameters())[k].grad
         out[f"clipae/gradstat/{k}"] = np.array([float(g_.double().sum()), float(g_.double().abs().sum()),
                                                 float(g_.double().pow(2).sum())])
+    # (2d) production geometries against the reference itself (logits sub-sampled 4x4 to keep the fixture small):
+    # UNet 2 x 3 x 256 x 256 (BASELINE config C2's image size; 2 images = 1024 8x16 tiles, the grid at which the bf16
+    # path switches to its weights-stationary / ring kernels) and ClipUnet 1 x 3 x 224 x 224 (config C5: 28 x 28 bottleneck)
+    def big_case(tag, model, x, t, extra_keys=()):
+        fill.fill_state_dict(model.state_dict())
+        model.eval()
+        with torch.no_grad():
+            out[f"{tag}/eval_logits_s4"] = npy(model(x)[:, :, ::4, ::4])
+        model.train()
+        lg = model(x)
+        ls_ = HybridLoss()(lg, t)
+        ls_.backward()
+        out[f"{tag}/train_logits_s4"] = npy(lg[:, :, ::4, ::4])
+        out[f"{tag}/ce_loss"] = npy(ls_)
+        out[f"{tag}/train_argmax_hist"] = np.bincount(npy(lg.argmax(1)).reshape(-1), minlength=3)
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g_ = p.grad
+            out[f"{tag}/gradstat/{k}"] = np.array([float(g_.double().sum()), float(g_.double().abs().sum()),
+                                                   float(g_.double().pow(2).sum())])
+        for k in extra_keys:
+            out[f"{tag}/grad/{k}"] = npy(dict(model.named_parameters())[k].grad)
+        # the reference's OWN bf16 deviation (its training loop runs under autocast): CPU autocast forward of the same
+        # state and batch, relative L2 against its fp32 logits -- the yardstick for the HIP bf16 path's deviation
+        for p_ in model.parameters():
+            p_.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lb = model(x).float()
+            lsb = HybridLoss()(lb, t)
+        lsb.backward()
+        d = (lb.detach() - lg.detach())[:, :, ::4, ::4]
+        out[f"{tag}/ref_bf16_autocast_rel_l2"] = np.array(
+            float(d.pow(2).sum().sqrt() / lg.detach()[:, :, ::4, ::4].pow(2).sum().sqrt()))
+        out[f"{tag}/ref_bf16_autocast_loss"] = npy(lsb)
+        for k in ("out.weight", "input.weight"):
+            out[f"{tag}/ref_bf16_autocast_grad_sq/{k}"] = np.array(
+                float(dict(model.named_parameters())[k].grad.double().pow(2).sum()))
+
+    big_case("unet_256", UNet(), T("u256.x", (2, 3, 256, 256)),
+             torch.from_numpy(fill.randint("u256.t", (2, 256, 256), 3)), ("out.weight", "input.weight", "dec4.up.bias"))
+    feats1 = T("clip224.feats", (1, 512), -1.0, 1.0)
+
+    class FakeExtractor1(nn.Module):
+        def __init__(self, train=False):
+            super().__init__()
+
+        def forward(self, x):
+            return feats1
+
+    ref_clip.ClipFeatureExtractor = FakeExtractor1
+    big_case("clip_224", ref_clip.ClipUnet(), T("clip224.x", (1, 3, 224, 224)),
+             torch.from_numpy(fill.randint("clip224.t", (1, 224, 224), 3)), ("out.weight",))
     np.savez_compressed(os.path.join(HERE, "models_r2.npz"), **out)
     print("models_r2.npz", len(out), "final loss", traj[-1], "median margin", float(out["trained/median_margin"]),
           "IoU vs target", float(out["trained/iou_vs_target"]))
