@@ -191,11 +191,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
-        try:
-            ctl = dist.new_group(backend="gloo")  # host-side agreement between ranks (never on the data path)
-        except Exception as e:  # noqa: BLE001  (no usable host interface: every rank then decides for itself)
-            print(f"[rank {rank}] no gloo control group ({e!r})", file=sys.stderr, flush=True)
-            ctl = None
+        # host-side agreement between ranks (never on the data path) -- only the in-graph RCCL capture needs one (all
+        # ranks must take the same fallback); the default N > 1 loop (eager) creates no second process group at all
+        want_graph = args.loop == "graph" or (args.loop == "auto" and world == 1)
+        if want_graph:
+            try:
+                ctl = dist.new_group(backend="gloo")
+            except Exception as e:  # noqa: BLE001  (no usable host interface: every rank then decides for itself)
+                print(f"[rank {rank}] no gloo control group ({e!r})", file=sys.stderr, flush=True)
+                ctl = None
 
     import hipseg
     from hipseg import ops

@@ -557,36 +557,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     }
 }
 
-// Slab reduction of the 3x3 weight gradient in ONE launch for any number of slabs: a block owns a 4(u) x 32(v) x 9 tile
-// and splits the S slabs over NS = 2 / 4 / 8 slices of 128 lanes (up to 1024 threads: enough loads in flight -- the
+// Slab reduction of the 3x3 weight gradient in ONE launch for any number of slabs: a block owns a UTL(u) x 32(v) x TG(taps)
+// tile and splits the S slabs over NS slices of UTL * 32 lanes (up to 1024 threads: enough loads in flight -- the
 // reduction is a chain of L2/HBM round trips otherwise); slice partials meet in LDS and are summed in slice order, then
-// written in the native (Cout=v, Cin=u, ky, kx) layout as 144-byte runs.  Replaced the in-place pre-reduce + reduce3
-// pair (two launches) for S >= 32 and the 16x16-tile reduce3 below it.
-template <int NS>
-__global__ __launch_bounds__(128 * NS) void wgrad_reduce3_wide_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                     int S, int CU, int CV, int CUp, int CVp) {
-    // tile = 4(u) x 32(v): a wave reads two full 128-byte slab rows per load instruction
-    __shared__ float red[NS][128][9];
-    const int tid = threadIdx.x, sl = tid >> 7, uv = tid & 127, u = uv >> 5, v = uv & 31;
-    const int u0 = blockIdx.y * 4, v0 = blockIdx.x * 32;
+// written in the native (Cout=v, Cin=u, ky, kx) layout.  UTL = 4, TG = 9 (144-byte output runs) for the layers whose
+// (CV/32) x (CU/4) grid fills the chip; the <= 64-channel layers, whose slab volume is the same 37.7 MB but whose 4 x 32
+// grid is only 8..64 blocks (one CU's 64 B/clk load path each: 15-16 us against 8 us for the wide layers), take UTL = 1
+// and TG = 3: (CV/32) x CU x 3 blocks.  Replaced the in-place pre-reduce + reduce3 pair (two launches).
+template <int NS, int UTL, int TG>
+__global__ __launch_bounds__(32 * UTL * NS) void wgrad_reduce3_wide_kernel(const float* __restrict__ slabs,
+                                                                           float* __restrict__ dw, int S, int CU, int CV,
+                                                                           int CUp, int CVp) {
+    // a wave reads full 128-byte slab rows (32 v) per load instruction
+    constexpr int UV = 32 * UTL;
+    __shared__ float red[NS][UV][TG];
+    const int tid = threadIdx.x, sl = tid / UV, uv = tid % UV, u = uv >> 5, v = uv & 31;
+    const int u0 = blockIdx.y * UTL, v0 = blockIdx.x * 32, t0 = blockIdx.z * TG;
     const size_t tstride = (size_t)CUp * CVp, sstride = 9 * tstride;
-    const float* src = slabs + (size_t)(u0 + u) * CVp + v0 + v;  // padded to 32: always in bounds
-    float acc[9];
+    const float* src = slabs + (size_t)(u0 + u) * CVp + v0 + v + t0 * tstride;  // padded to 32: always in bounds
+    float acc[TG];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int t = 0; t < TG; ++t) acc[t] = 0.f;
     for (int s = sl; s < S; s += NS) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] += src[s * sstride + t * tstride];
+        for (int t = 0; t < TG; ++t) acc[t] += src[s * sstride + t * tstride];
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[sl][uv][t] = acc[t];
+    for (int t = 0; t < TG; ++t) red[sl][uv][t] = acc[t];
     __syncthreads();
-    for (int o = tid; o < 128 * 9; o += 128 * NS) {  // index within the tile: vv * 36 + uu * 9 + t
-        const int vv = o / 36, rem = o % 36, uu = rem / 9, t = rem % 9;
+    for (int o = tid; o < UV * TG; o += UV * NS) {  // index within the tile: vv * (UTL * TG) + uu * TG + t
+        const int vv = o / (UTL * TG), rem = o % (UTL * TG), uu = rem / TG, t = rem % TG;
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; ++k) sum += red[k][uu * 32 + vv][t];
-        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t] = sum;
+        if (v0 + vv < CV && u0 + uu < CU) dw[((size_t)(v0 + vv) * CU + u0 + uu) * 9 + t0 + t] = sum;
     }
 }
 
@@ -714,12 +718,18 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
         int S = pl.S, sstep = 1;
         if (mode == HIPSEG_CONV3) {  // one launch for any number of slabs
             const dim3 rg(cdiv(CV, 32), cdiv(CU, 4));  // (CVp, CUp are multiples of 32)
-            if (pl.S >= 8)
-                hipLaunchKernelGGL(wgrad_reduce3_wide_kernel<8>, rg, dim3(1024), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp, pl.CVp);
+            if (pl.S >= 32 && rg.x * rg.y < 128)  // many slabs of a small weight tensor: narrow tiles, 3 tap groups
+                hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<32, 1, 3>), dim3(rg.x, CU, 3), dim3(1024), 0, s, slabs, dw, pl.S,
+                                   CU, CV, pl.CUp, pl.CVp);
+            else if (pl.S >= 8)
+                hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<8, 4, 9>), rg, dim3(1024), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp,
+                                   pl.CVp);
             else if (pl.S >= 4)
-                hipLaunchKernelGGL(wgrad_reduce3_wide_kernel<4>, rg, dim3(512), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp, pl.CVp);
+                hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<4, 4, 9>), rg, dim3(512), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp,
+                                   pl.CVp);
             else
-                hipLaunchKernelGGL(wgrad_reduce3_wide_kernel<2>, rg, dim3(256), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp, pl.CVp);
+                hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<2, 4, 9>), rg, dim3(256), 0, s, slabs, dw, pl.S, CU, CV, pl.CUp,
+                                   pl.CVp);
             HS_LAUNCH_CHECK("wgrad_reduce(wide)");
             continue;
         }
