@@ -68,6 +68,8 @@ struct ConvArgs {
     const void* in1;
     const void* wp;
     const float* bias;
+    const float* post_scale;  // inference epilogue (hipseg_conv_affine_relu): y = relu(conv * post_scale[n] + bias[n]),
+                              // `bias` then holds the folded shift; NULL = plain conv + bias
     void* out0;
     void* out1;
     float* stats;
@@ -154,8 +156,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     float* tile = reinterpret_cast<float*>(smem) + wave * (32 * TN);
 
     constexpr int GPW = MT / 2;  // 64-row statistics groups per wave (a 256-row tile has 4)
-    float bv[NTL], ssum[GPW][NTL], ssq[GPW][NTL];
+    float bv[NTL], sc[NTL], ssum[GPW][NTL], ssq[GPW][NTL];
     int ncol[NTL];
+    const bool aff = p.post_scale != nullptr;  // fused inference epilogue: * scale + shift, ReLU
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
         ncol[j] = wn * (BN / WN) + j * 32 + r;
@@ -163,6 +166,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
         int co = n;
         if (MODE == HIPSEG_CONVT) co = n % p.N0;
         bv[j] = (n < p.N && p.bias) ? p.bias[co] : 0.f;
+        sc[j] = (aff && n < p.N) ? p.post_scale[co] : 1.f;
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
             ssum[g][j] = 0.f;
@@ -182,7 +186,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float v = acc[i][j][e] + bv[j];
+                float v = fmaf(acc[i][j][e], sc[j], bv[j]);  // (sc = 1: exactly acc + bias)
+                if (aff) v = fmaxf(v, 0.f);
                 tile[rr * TN + swz_col(rr, j * 32 + r)] = v;
                 if (nok && yb + (rr >> 4) < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                     ssum[i / 2][j] += v;
@@ -1116,6 +1121,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
     }
     const int n = wn * 32 + r;  // this lane's output channel (accumulator column); N == Np is a launch condition
     const float bv = p.bias ? p.bias[n] : 0.f;
+    const bool aff = p.post_scale != nullptr;  // fused inference epilogue (see ConvArgs)
+    const float scl = aff ? p.post_scale[n] : 1.f;
 
     // ---- per-lane DMA constants: pixel (py, px) of the halo tile for each 64-pixel group
     int poff[NG], pyx[NG];
@@ -1271,7 +1278,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int e = half * 8 + e8;
                         const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
-                        const float v = acc[i][e] + bv;
+                        float v = fmaf(acc[i][e], scl, bv);  // (scl = 1: exactly acc + bias)
+                        if (aff) v = fmaxf(v, 0.f);
                         reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
                         ssum += v;
                         ssq += v * v;
@@ -1281,7 +1289,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int e = half * 8 + e8;
                         const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = acc[i][e] + bv;
+                        float v = fmaf(acc[i][e], scl, bv);
+                        if (aff) v = fmaxf(v, 0.f);
                         reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
                         if (y0 + yr + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                             ssum += v;
@@ -1466,9 +1475,9 @@ extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N
     return hipseg_conv_mtiles(B, H, W);
 }
 
-extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
-                                 const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
-                                 float* stats, int B, int H, int W, hipseg_stream_t stream) {
+static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const void* in1, int C1, const void* wp,
+                           const float* bias, const float* post_scale, void* out0, int N0, void* out1, int N1,
+                           float* stats, int B, int H, int W, hipseg_stream_t stream) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_igemm: bad dtype %d", dtype);
     HS_REQUIRE(mode >= HIPSEG_CONV3 && mode <= HIPSEG_CONVT, "conv_igemm: bad mode %d", mode);
     HS_REQUIRE(in0 && wp && out0 && C0 > 0 && N0 > 0, "conv_igemm: null operand or empty channel range");
@@ -1481,6 +1490,7 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
     a.in1 = in1;
     a.wp = wp;
     a.bias = bias;
+    a.post_scale = post_scale;
     a.out0 = out0;
     a.out1 = out1;
     a.stats = stats;
@@ -1553,4 +1563,20 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
         return launch_mode<bf16>(a, mode, bn, s);
     }
     return launch_mode<float>(a, mode, bn, s);
+}
+
+extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* in1, int C1,
+                                 const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
+                                 float* stats, int B, int H, int W, hipseg_stream_t stream) {
+    return conv_igemm_impl(dtype, mode, in0, C0, in1, C1, wp, bias, nullptr, out0, N0, out1, N1, stats, B, H, W, stream);
+}
+
+// Inference form of conv3x3 -> BatchNorm(running statistics) -> ReLU in ONE kernel: the per-channel affine is applied to
+// the fp32 accumulators in the epilogue, so neither the pre-normalisation tensor nor a second pass over it exists.
+extern "C" int hipseg_conv_affine_relu(int dtype, const void* in0, int C0, const void* in1, int C1, const void* wp,
+                                       const float* scale, const float* shift, void* out, int N, int B, int H, int W,
+                                       hipseg_stream_t stream) {
+    HS_REQUIRE(scale && shift, "conv_affine_relu: scale and shift are required");
+    return conv_igemm_impl(dtype, HIPSEG_CONV3, in0, C0, in1, C1, wp, shift, scale, out, N, nullptr, 0, nullptr, B, H, W,
+                           stream);
 }

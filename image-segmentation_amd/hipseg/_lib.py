@@ -39,6 +39,7 @@ PROTOTYPES = {
     "hipseg_pack_desc_fill": (I, [P, I, P, P, P, I, I, I, I, I]),
     "hipseg_pack_batch": (I, [P, I, I, L, P]),
     "hipseg_conv_igemm": (I, [I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, P]),
+    "hipseg_conv_affine_relu": (I, [I, P, I, P, I, P, P, P, P, I, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
     "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),
     "hipseg_bn_finalize": (I, [P, I, I, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),

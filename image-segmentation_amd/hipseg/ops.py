@@ -265,14 +265,28 @@ class _BN:
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
 
 
-def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False):
+def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False, inference=False):
     """conv3x3 (+bias, +BN batch statistics in the epilogue) -> BN finalize -> BN-apply+ReLU(+pool).
-    Returns (raw conv output, activated output, bn state, data-gradient weight operand or None)."""
+    Returns (raw conv output, activated output, bn state, data-gradient weight operand or None).
+    `inference` (eval mode and no gradient wanted: the validation loops, model_wrappers.py:193-215) without a pool runs
+    conv -> running-statistics BatchNorm -> ReLU as ONE kernel (hipseg_conv_affine_relu): no pre-normalisation tensor,
+    no second pass; returns (None, activated output, None, None)."""
     B, _, H, W = x0.shape
     cout = w.shape[0]
     dev = x0.device
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
+    if inference and not train and not pool:
+        bn = _BN(cout, dev)
+        s = _stream()
+        L.bn_eval_params(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, cout, ptr(bn.mean), ptr(bn.invstd),
+                         ptr(bn.scale), ptr(bn.shift), s)
+        shift = torch.addcmul(bn.shift, b.detach().float(), bn.scale) if b is not None else bn.shift  # + conv bias * scale
+        act = nhwc_empty(B, cout, H, W, x0.dtype, dev)
+        key = f"conv_igemm<{'bf16' if dt == L.BF16 else 'f32'},CONV3,BN{128 if cout > 64 else (64 if cout > 32 else 32)}>"
+        _timed(key, 2.0 * B * H * W * cout * (c0 + c1) * 9, L.conv_affine_relu, dt, ptr(x0), c0, ptr(x1), c1,
+               ptr(_pack_conv(w, dt, False)), ptr(bn.scale), ptr(shift), ptr(act), cout, B, H, W, s)
+        return None, act, None, None
     if need_t:
         wp, wpt = _pack_conv_both(w, dt)
     else:
@@ -321,17 +335,26 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta):
     return draw, sums[C:], sums[:C], dbias
 
 
+_NO_FUSED_INFERENCE = bool(os.environ.get("HIPSEG_NO_FUSED_INFERENCE"))  # A/B switch (scripts/bench_infer.py)
+
+
 class ConvBlockFn(torch.autograd.Function):
     """[cat(x0,x1)] -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU [-> MaxPool2d(2,2)]
     = ConvBlock / ConvBlockDownsample / the conv half of ConvBlockUpsampleSkip
     (models/processing_blocks.py:40-52, 69-77, 108-109)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool):
+    def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool,
+                no_grad=False):
         dt = _dt(x0)
-        grad = any(ctx.needs_input_grad)  # (grad mode itself is off inside Function.forward)
-        raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad)
-        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad)
+        # (grad mode is off inside Function.forward, and needs_input_grad stays True for parameters under
+        # torch.no_grad(): the caller passes whether a graph is being recorded at all)
+        grad = any(ctx.needs_input_grad) and not no_grad
+        inf = not grad and not train and not _NO_FUSED_INFERENCE  # nothing saved, no backward: fused inference kernels
+        raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad, inf)
+        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf)
+        if inf:
+            return out
         ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
         ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
         ctx.small = (b1, g1, be1, b2, g2, be2)  # leaf parameters: only their gradient destinations are needed
@@ -369,7 +392,7 @@ class ConvBlockFn(torch.autograd.Function):
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
             dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
             igemm(dt, L.CONV3, draw1, C, None, 0, wp1t, None, dx0, c0, dx1, c1, None, B, H, W)
-        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None)
+        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None, None)
 
 
 class ConvT2x2Fn(torch.autograd.Function):

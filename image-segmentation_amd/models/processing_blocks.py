@@ -33,7 +33,7 @@ def _double_conv(seq, x, skip, pool):
     stats = (n1.running_mean, n1.running_var, n1.num_batches_tracked, n2.running_mean, n2.running_var,
              n2.num_batches_tracked)
     return ops.ConvBlockFn.apply(x, skip, c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight,
-                                 n2.bias, *stats, train, pool)
+                                 n2.bias, *stats, train, pool, not torch.is_grad_enabled())
 
 
 def _conv_seq(cin, cout, k, pad):

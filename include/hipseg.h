@@ -113,6 +113,17 @@ int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, const void* 
                       const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
                       float* stats, int B, int H, int W, hipseg_stream_t stream);
 
+/* ---- inference: conv3x3 -> BatchNorm2d (running statistics) -> ReLU in one kernel ------------
+ * out = relu(conv3x3(cat(in0, in1)) * scale[n] + shift[n]), the affine applied to the fp32 accumulators in the
+ * epilogue.  The caller folds the conv bias and the BatchNorm into the two vectors:
+ *   scale = gamma / sqrt(running_var + eps),  shift = beta + (conv_bias - running_mean) * scale.
+ * Same operands, packing and dispatch as hipseg_conv_igemm(HIPSEG_CONV3).
+ * replaces: Conv2d -> BatchNorm2d.eval() -> ReLU of ConvBlock (models/processing_blocks.py:42-48) under
+ *           model.eval() + torch.no_grad() (the validation loops, models/model_wrappers.py:193-215). */
+int hipseg_conv_affine_relu(int dtype, const void* in0, int C0, const void* in1, int C1, const void* wp,
+                            const float* scale, const float* shift, void* out, int N, int B, int H, int W,
+                            hipseg_stream_t stream);
+
 /* ---- weight gradient (MFMA, split over pixel chunks) --------------------------------
  * G[tap][u][v] = sum_pixels P[n, tap(y,x), u] * Q[n, y, x, v]
  *   mode HIPSEG_CONV3 : P = layer input (p0|p1 dual source, CU = Cin), Q = dY (CV = Cout),

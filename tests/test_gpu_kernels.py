@@ -118,6 +118,33 @@ def test_conv3_fwd_stats(hs, prec, td, dt, case):
 
 @pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3_affine_relu_inference_epilogue(hs, prec, td, dt, case):
+    """hipseg_conv_affine_relu == relu(conv3x3(x) * scale + shift) (conv -> eval BatchNorm -> ReLU folded into the conv
+    epilogue; processing_blocks.py:42-48 under model.eval()), on every dispatch shape of the conv tests"""
+    B, C0, C1, Cout, H, W = case
+    L, ops = hs.L, hs.ops
+    x0 = rnd(T("k.x0", (B, C0, H, W)), td)
+    x1 = rnd(T("k.x1", (B, C1, H, W)), td) if C1 else None
+    w = T("k.w", (Cout, C0 + C1, 3, 3), -0.3, 0.3)
+    scale = T("k.sc", (Cout,), 0.2, 1.5)
+    scale[::3] *= -1.0  # negative BatchNorm weights exist too
+    shift = T("k.sh", (Cout,), -1.0, 1.0)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    want = torch.relu(F.conv2d(xin, rnd(w, td), None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    dx0 = to_dev_nhwc(x0, td)
+    dx1 = to_dev_nhwc(x1, td) if C1 else None
+    wp = ops._pack_conv(w.cuda(), dt, False)
+    out = ops.nhwc_empty(B, Cout, H, W, td, "cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    L.conv_affine_relu(dt, ops.ptr(dx0), C0, ops.ptr(dx1), C1, ops.ptr(wp), ops.ptr(sc), ops.ptr(sh), ops.ptr(out), Cout,
+                       B, H, W, ops._stream())
+    torch.cuda.synchronize()
+    check(out, want, td, what="conv3 + affine + relu")
+    assert float(out.float().min()) >= 0.0 and float((out == 0).float().mean()) > 0.05  # the ReLU really clipped
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv3_dgrad_wgrad(hs, prec, td, dt, case):
     B, C0, C1, Cout, H, W = case
     L, ops = hs.L, hs.ops

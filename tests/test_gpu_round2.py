@@ -147,6 +147,40 @@ def test_clip_unet_224_vs_reference_golden(M, golden):
     _production_geometry_case(M, g, "clip_224", m.cuda(), x, t, ("out.weight",), dead_prefix="bottleneck.")
 
 
+def test_inference_path_fused_conv_bn_relu_matches_the_unfused_eval_forward(M, golden):
+    """model.eval() + torch.no_grad() (the validation loops, model_wrappers.py:193-215) takes the one-kernel
+    conv -> BatchNorm(running statistics) -> ReLU path (hipseg_conv_affine_relu); with gradients enabled the same eval
+    forward keeps the separate kernels (their backward needs the pre-normalisation tensor).  Both must agree -- and the
+    fused one is what the reference goldens' eval logits are checked against in the other tests."""
+    g = golden("models_r2")
+    m = _trained_unet(M, g).eval()
+    x = _blob_inputs("blob.test", 4).cuda()
+    with M.hipseg.precision_mode("fp32"):
+        with torch.no_grad():
+            fused = m(x)
+        with torch.enable_grad():
+            unfused = m(x)
+        assert unfused.requires_grad and not fused.requires_grad
+        assert float((fused - unfused.detach()).abs().max()) <= 2e-5
+        assert np.abs(fused.cpu().numpy() - g["trained/eval_logits"]).max() <= 1e-4 * max(1.0, np.abs(g["trained/eval_logits"]).max())
+    with torch.autocast("cuda"):
+        with torch.no_grad():
+            fb = m(x).float()
+        with torch.enable_grad():
+            ub = m(x).float().detach()
+    ref = g["trained/eval_logits"]
+    # the fused form skips one bf16 rounding (of the pre-normalisation tensor) per layer: at least as close to fp32
+    ef = float(np.sqrt(((fb.cpu().numpy() - ref) ** 2).sum() / (ref ** 2).sum()))
+    eu = float(np.sqrt(((ub.cpu().numpy() - ref) ** 2).sum() / (ref ** 2).sum()))
+    assert ef <= 1.1 * eu + 1e-3, (ef, eu)
+    assert iou_masks(fb.argmax(1).cpu().numpy(), ref.argmax(1)) >= 1.0 - 1e-2
+    # and nothing of the BatchNorm state moved in eval mode
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(g[f"trained/state/{k}"]), k
+
+
 def _trained_unet(M, g):
     """the reference-trained state: oracle.fill weights everywhere, dec4.* / out.* and every BN buffer from the fixture"""
     m = M.un.UNet()
