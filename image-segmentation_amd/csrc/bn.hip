@@ -523,6 +523,28 @@ extern "C" int hipseg_bn_eval_params(const float* gamma, const float* beta, cons
     return HIPSEG_OK;
 }
 
+// scale / shift of conv -> eval BatchNorm folded for hipseg_conv_affine_relu (one launch per layer)
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               const float* conv_bias, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] * (1.f / sqrtf(rv[c] + eps));
+        const float sh = beta[c] - rm[c] * sc;  // exactly bn_eval_params' shift ...
+        scale[c] = sc;
+        shift[c] = conv_bias ? fmaf(conv_bias[c], sc, sh) : sh;  // ... + conv bias * scale
+    }
+}
+
+extern "C" int hipseg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                              const float* conv_bias, float eps, int C, float* scale, float* shift,
+                              hipseg_stream_t stream) {
+    HS_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gamma, beta,
+                       running_mean, running_var, conv_bias, eps, C, scale, shift);
+    HS_LAUNCH_CHECK("bn_fold");
+    return HIPSEG_OK;
+}
+
 extern "C" int hipseg_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, int B,
                                     int H, int W, int C, int pool, hipseg_stream_t stream) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_relu_apply: bad dtype");

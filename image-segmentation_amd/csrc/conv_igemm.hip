@@ -125,7 +125,7 @@ __device__ __forceinline__ constexpr int tap_off(int tap) {
 // instead turns its 32-pixel x (32*NTL)-channel sub-tile through a private LDS tile (fp32) and
 // writes full 16-byte channel vectors per lane: 128 contiguous bytes per pixel for a 64-channel wave tile.
 // Also adds the bias and reduces the BatchNorm partial statistics (sum, sum of squares per channel).
-template <typename T, int MODE, int BN, int NW, int THT = 16>
+template <typename T, int MODE, int BN, int NW, int THT = 16, bool AFF = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
                                               f32x16 (&acc)[WG<BN, NW, THT>::MT][WG<BN, NW, THT>::NTL],
                                               unsigned char* smem, int mtile, int img, int y0, int x0, int n0) {
@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     constexpr int GPW = MT / 2;  // 64-row statistics groups per wave (a 256-row tile has 4)
     float bv[NTL], sc[NTL], ssum[GPW][NTL], ssq[GPW][NTL];
     int ncol[NTL];
-    const bool aff = p.post_scale != nullptr;  // fused inference epilogue: * scale + shift, ReLU
+    constexpr bool aff = AFF;  // fused inference epilogue (compile-time: the training kernels carry none of it)
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
         ncol[j] = wn * (BN / WN) + j * 32 + r;
@@ -186,8 +186,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                float v = fmaf(acc[i][j][e], sc[j], bv[j]);  // (sc = 1: exactly acc + bias)
-                if (aff) v = fmaxf(v, 0.f);
+                float v = aff ? fmaxf(fmaf(acc[i][j][e], sc[j], bv[j]), 0.f) : acc[i][j][e] + bv[j];
                 tile[rr * TN + swz_col(rr, j * 32 + r)] = v;
                 if (nok && yb + (rr >> 4) < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                     ssum[i / 2][j] += v;
@@ -274,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     }
 }
 
-template <typename T, int MODE, int BN>
+template <typename T, int MODE, int BN, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int G = KT<T>::G, KC = KT<T>::KC, KG = KC / G;
     constexpr int HH = Geo<MODE>::HH, HW = Geo<MODE>::HW, NT = Geo<MODE>::NT, NPIX = HH * HW;
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
-    conv_epilogue<T, MODE, BN, 4>(p, acc, smem, mtile, img, y0, x0, n0);
+    conv_epilogue<T, MODE, BN, 4, 16, AFF>(p, acc, smem, mtile, img, y0, x0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -462,7 +461,7 @@ struct DmaBufs {
 // THT = tile rows: 16 (256-pixel tile) or 32 (512-pixel "tall" tile: every wave owns a 128-row x 64-channel block,
 // 0.75 LDS fragment reads per MFMA instead of 1.0, and the weight chunk is amortised over twice the pixels --
 // the main loop is LDS-bandwidth bound: fragment reads + DMA writes share the LDS port with nothing to spare).
-template <int MODE, int BN, int THT = 16>
+template <int MODE, int BN, int THT = 16, bool AFF = false>
 __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>::value == 8 ? 1 : 2)) void conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int NW = DmaWaves<BN, THT>::value, NBUF = DmaBufs<BN, THT>::value, DIST = NBUF - 1;
@@ -697,7 +696,7 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>
         if (moreB) writeB(cur);  // `cur` already names the next chunk's slot (free since the barrier above)
     }
 
-    if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+    if (!(p.debug & 8)) conv_epilogue<bf16, MODE, BN, NW, THT, AFF>(p, acc, smem, mtile, img, y0, x0, n0);
 #else
     (void)p;
 #endif
@@ -886,7 +885,7 @@ struct A64Geo {
     static_assert(A_BYTES % 1024 == 0 && LDS <= 160 * 1024, "geometry");
 };
 
-template <int THT, int SO>
+template <int THT, int SO, bool AFF = false>
 __global__ __launch_bounds__(512, 1) void conv3_ring64_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     typedef A64Geo<THT, SO> G;
@@ -1053,7 +1052,7 @@ __global__ __launch_bounds__(512, 1) void conv3_ring64_kernel(ConvArgs p) {
             if (moreB) writeB((kc + 1) & 1);
         }
     }
-    conv_epilogue<bf16, MODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+    conv_epilogue<bf16, MODE, BN, NW, THT, AFF>(p, acc, smem, mtile, img, y0, x0, n0);
 #else
     (void)p;
 #endif
@@ -1086,7 +1085,7 @@ struct WsGeo {
     static_assert(NOCT % NW == 0 && LDS <= 80 * 1024, "geometry");
 };
 
-template <int KCH, int NB, bool DBG>
+template <int KCH, int NB, bool DBG, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int total_tiles, int tiles_y8) {
     typedef bf16 T;
     typedef WsGeo<KCH, NB> G;
@@ -1121,7 +1120,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
     }
     const int n = wn * 32 + r;  // this lane's output channel (accumulator column); N == Np is a launch condition
     const float bv = p.bias ? p.bias[n] : 0.f;
-    const bool aff = p.post_scale != nullptr;  // fused inference epilogue (see ConvArgs)
+    constexpr bool aff = AFF;  // fused inference epilogue (see ConvArgs); compile-time
     const float scl = aff ? p.post_scale[n] : 1.f;
 
     // ---- per-lane DMA constants: pixel (py, px) of the halo tile for each 64-pixel group
@@ -1278,8 +1277,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int e = half * 8 + e8;
                         const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
-                        float v = fmaf(acc[i][e], scl, bv);  // (scl = 1: exactly acc + bias)
-                        if (aff) v = fmaxf(v, 0.f);
+                        const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
                         reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
                         ssum += v;
                         ssq += v * v;
@@ -1289,8 +1287,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int e = half * 8 + e8;
                         const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                        float v = fmaf(acc[i][e], scl, bv);
-                        if (aff) v = fmaxf(v, 0.f);
+                        const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
                         reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
                         if (y0 + yr + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                             ssum += v;
@@ -1332,7 +1329,12 @@ int launch_wstat(const ConvArgs& a, hipStream_t s) {
     const int tiles_y8 = cdiv(a.H, G::THS);
     const long total = (long)a.B * a.tiles_x * tiles_y8;
     const long grid = 2 * a.ncu;  // wstat_grid(): total >= 4 * ncu
-    if (a.debug)
+    if (a.post_scale) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false, true>), (size_t)G::LDS))
+            return rc;
+        hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, false, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a,
+                           (int)total, tiles_y8);
+    } else if (a.debug)
         hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a, (int)total,
                            tiles_y8);
     else
@@ -1357,6 +1359,15 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
+    if constexpr (MODE == HIPSEG_CONV3) {
+        if (a.post_scale) {  // inference epilogue: its own instantiation
+            if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<MODE, BN, THT, true>), (size_t)lds))
+                return rc;
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN, THT, true>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
+            HS_LAUNCH_CHECK("conv_igemm_dma(affine)");
+            return HIPSEG_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, BN, THT>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm_dma");
     return HIPSEG_OK;
@@ -1384,7 +1395,11 @@ int launch_ring64(const ConvArgs& a0, hipStream_t s) {
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
-    hipLaunchKernelGGL((conv3_ring64_kernel<THT, SO>), dim3((unsigned)grid), dim3(512), G::LDS, s, a);
+    if (a.post_scale) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_ring64_kernel<THT, SO, true>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_ring64_kernel<THT, SO, true>), dim3((unsigned)grid), dim3(512), G::LDS, s, a);
+    } else
+        hipLaunchKernelGGL((conv3_ring64_kernel<THT, SO>), dim3((unsigned)grid), dim3(512), G::LDS, s, a);
     HS_LAUNCH_CHECK("conv3_ring64");
     return HIPSEG_OK;
 }
@@ -1414,6 +1429,13 @@ int launch(const ConvArgs& a, hipStream_t s) {
     const size_t scratch = (size_t)4 * 32 * (BN / WN) * sizeof(float);  // per-wave fp32 transpose tiles (epilogue)
     if (lds < scratch) lds = scratch;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
+    if constexpr (MODE == HIPSEG_CONV3) {
+        if (a.post_scale) {  // inference epilogue: its own instantiation
+            hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BN, true>), dim3((unsigned)grid), dim3(256), lds, s, a);
+            HS_LAUNCH_CHECK("conv_igemm(affine)");
+            return HIPSEG_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BN>), dim3((unsigned)grid), dim3(256), lds, s, a);
     HS_LAUNCH_CHECK("conv_igemm");
     return HIPSEG_OK;

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),
     "hipseg_bn_finalize": (I, [P, I, I, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "hipseg_bn_eval_params": (I, [P, P, P, P, c_float, I, P, P, P, P, P]),
+    "hipseg_bn_fold": (I, [P, P, P, P, P, c_float, I, P, P, P]),
     "hipseg_bn_relu_apply": (I, [I, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_bn_bwd_blocks": (I, [I, I, I, I, I, I]),
     "hipseg_bn_bwd_reduce": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),

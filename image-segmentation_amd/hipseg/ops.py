@@ -277,15 +277,13 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
     if inference and not train and not pool:
-        bn = _BN(cout, dev)
+        fold = _f32(2 * cout, dev)  # [scale | shift]: BatchNorm (running statistics) and the conv bias folded
         s = _stream()
-        L.bn_eval_params(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, cout, ptr(bn.mean), ptr(bn.invstd),
-                         ptr(bn.scale), ptr(bn.shift), s)
-        shift = torch.addcmul(bn.shift, b.detach().float(), bn.scale) if b is not None else bn.shift  # + conv bias * scale
+        L.bn_fold(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(b), BN_EPS, cout, ptr(fold), ptr(fold[cout:]), s)
         act = nhwc_empty(B, cout, H, W, x0.dtype, dev)
         key = f"conv_igemm<{'bf16' if dt == L.BF16 else 'f32'},CONV3,BN{128 if cout > 64 else (64 if cout > 32 else 32)}>"
         _timed(key, 2.0 * B * H * W * cout * (c0 + c1) * 9, L.conv_affine_relu, dt, ptr(x0), c0, ptr(x1), c1,
-               ptr(_pack_conv(w, dt, False)), ptr(bn.scale), ptr(shift), ptr(act), cout, B, H, W, s)
+               ptr(_pack_conv(w, dt, False)), ptr(fold), ptr(fold[cout:]), ptr(act), cout, B, H, W, s)
         return None, act, None, None
     if need_t:
         wp, wpt = _pack_conv_both(w, dt)

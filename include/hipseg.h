@@ -153,6 +153,10 @@ int hipseg_bn_finalize(float* stats, int mtiles, int C, double count, const floa
 int hipseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
                           const float* running_var, float eps, int C, float* mean, float* invstd,
                           float* scale, float* shift, hipseg_stream_t stream);
+/* scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale + conv_bias * scale (conv_bias may be
+ * NULL): the two vectors hipseg_conv_affine_relu takes, one launch per layer. */
+int hipseg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                   const float* conv_bias, float eps, int C, float* scale, float* shift, hipseg_stream_t stream);
 /* y = relu(x*scale + shift); pool != 0 additionally applies MaxPool2d(2,2) and writes the
  * pooled (H/2 x W/2) tensor only.  (processing_blocks.py:44-45,47-48,73) */
 int hipseg_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y,
