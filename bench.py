@@ -110,7 +110,7 @@ _PMC_FILE = "r02_pmc_traffic.json"
 # roofline key -> (kernels whose launches are counted, helper kernels whose bytes are added to them)
 _PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": (("wgrad_dma_kernel<9,",), ("wgrad_reduce3_wide",)),
                 "conv_igemm<bf16,CONV3,BN128>": (("conv3_ring64_kernel", "conv_igemm_dma_kernel<0, 128,",
-                                                  "conv_igemm_dma_kernel<0, 64, 16>"), ())}
+                                                  "conv_igemm_dma_kernel<0, 64, 16"), ())}
 _PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "bn.hip", "common.h")
 
 
