@@ -52,7 +52,14 @@ def _tdtype(prec):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of the current stream of the current device.  (torch.cuda.current_stream().cuda_stream builds a Stream
+    object and resolves the device index in Python: 9.5 us per call, 0.8 ms of host time per train step at one call
+    per kernel launch -- scripts/prof_python.py)"""
+    return _raw_stream(_cur_device())
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
 
 
 def _require_gpu(t):

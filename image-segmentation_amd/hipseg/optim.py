@@ -100,6 +100,9 @@ class Adam(torch.optim.Optimizer):
                         ptr(grad_scale.float() if grad_scale is not None else None),
                         float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                         _stream())
+            # the kernel wrote the parameters through raw pointers: tell autograd (saved-tensor checks, the packed-weight
+            # cache and anything else keyed on ._version must see an in-place update, as after torch.optim.Adam.step)
+            torch.autograd.graph.increment_version(active)
         return loss
 
     # ------------------------------------------------------------------ checkpointing (torch.optim.Adam's layout)

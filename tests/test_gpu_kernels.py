@@ -398,6 +398,7 @@ def test_hip_adam_matches_torch_adam():
     kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
     ref = torch.optim.Adam(ref_p, **kw)
     opt = Adam(dev_p, **kw)
+    v0 = [p._version for p in dev_p]
     scale = torch.tensor([1024.0], device="cuda")
     applied = 0
     for it in range(7):
@@ -450,6 +451,8 @@ def test_hip_adam_matches_torch_adam():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     assert opt.step_count() == applied + 1 + 3
+    # the kernel writes through raw pointers; autograd must still see in-place updates (as after torch.optim.Adam.step)
+    assert all(p._version > v for p, v in zip(dev_p[:-1], v0)) and dev_p[-1]._version == v0[-1]
     for p, rp in zip(dev_p, ref_p):
         np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=5e-5, atol=5e-6)
 
