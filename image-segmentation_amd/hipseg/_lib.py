@@ -4,6 +4,7 @@ The product path has NO CPU fallback: if the library is missing or fails to load
 importing this module raises, and every op raises RuntimeError on a non-zero return.
 """
 import ctypes
+import functools
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
@@ -106,7 +107,9 @@ class HipsegError(RuntimeError):
 def _wrap(name):
     fn = getattr(lib, name)
     if name in _PURE:
-        return fn
+        # pure functions of shapes (and of the current device's CU count: one device per process): memoised, a ctypes
+        # round trip costs 2-3 us of host time per kernel launch otherwise
+        return fn if name == "hipseg_last_error" else functools.lru_cache(maxsize=8192)(fn)
 
     def call(*a):
         rc = fn(*a)
