@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/s of one full U-Net train step on synthetic 3x256x256 batches
 (BASELINE.json configs[1]: UNet, batch 16 per GPU, bf16) -- forward + cross-entropy + backward
-(+ bucketed RCCL gradient all-reduce for N > 1) + GradScaler/Adam step, inputs resident in HBM.
+(+ bucketed RCCL gradient all-reduce for N > 1, overlapped with backward) + GradScaler/Adam step, inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -47,11 +47,13 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet"])
     ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "auto"),
-                    choices=["auto", "eager", "graph", "splitgraph"],
-                    help="auto: graph for one GPU, eager for N > 1 (measured on one MI355X the two run at the same "
-                         "rate -- 4.494 vs 4.498 ms/step plain, 4.82 vs 4.76 with the 1-rank DDP rehearsal: the step is "
-                         "GPU-bound -- so N > 1 takes the form that needs no RCCL-inside-hipGraph capture, which a "
-                         "1-GPU development box cannot exercise with real peers).  graph: the whole step is ONE "
+                    choices=["auto", "eager", "graph", "splitgraph", "evgraph"],
+                    help="auto: graph for one GPU, evgraph for N > 1.  evgraph: hipGraph(fwd+bwd) with one EXTERNAL "
+                         "event-record node per gradient bucket -> the bucketed RCCL all-reduces are issued EAGERLY on a "
+                         "side stream right after the graph launch, each behind its bucket's event, i.e. overlapped with "
+                         "the replayed backward -> hipGraph(optimizer): the host cost of two graph launches, and no RCCL "
+                         "call inside any capture (which a 1-GPU development box cannot exercise with real peers); falls "
+                         "back to eager if the capture fails.  graph: the whole step is ONE "
                          "hipGraph replay; for N > 1 the bucketed RCCL all-reduces are captured inside it as side-stream "
                          "branches overlapped with backward.  eager: Python launches every kernel each step (all-reduce "
                          "overlapped from autograd hooks on a side stream).  splitgraph (N > 1 only): hipGraph(fwd+bwd+"
@@ -193,7 +195,7 @@ def main():
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
         # host-side agreement between ranks (never on the data path) -- only the in-graph RCCL capture needs one (all
         # ranks must take the same fallback); the default N > 1 loop (eager) creates no second process group at all
-        want_graph = args.loop == "graph" or (args.loop == "auto" and world == 1)
+        want_graph = args.loop == "graph"
         if want_graph:
             try:
                 ctl = dist.new_group(backend="gloo")
@@ -218,16 +220,17 @@ def main():
         model = getattr(un, args.model)().to(dev).train()
     loop = args.loop
     if loop == "auto":
-        loop = "eager" if world > 1 else "graph"
-    if loop == "splitgraph" and not ddp:
+        loop = "evgraph" if ddp else "graph"
+    if loop in ("splitgraph", "evgraph") and not ddp:
         loop = "graph"
-    use_graph = loop in ("graph", "splitgraph")
+    use_graph = loop in ("graph", "splitgraph", "evgraph")
     split = loop == "splitgraph"
+    evg = loop == "evgraph"
     # graph / eager: gradients are reduced bucket by bucket from autograd hooks on a side stream, overlapped with
     # backward (north star); splitgraph: explicit pack + all-reduce between two graphs
     # 8 MB buckets (torch DDP's default is 25): the big dec1 / bottleneck / enc3 gradients arrive mid-backward, and a
     # smaller cap starts their reduction earlier; xGMI all-reduce latency (~tens of us) is paid 5 times instead of 3
-    net = HipDDP(model, overlap=not split, force_collectives=force,
+    net = HipDDP(model, overlap=("events" if evg else not split), force_collectives=force,
                  bucket_cap_mb=float(os.environ.get("HIPSEG_BUCKET_MB", "8"))) if ddp else model
     crit = HybridLoss()
     # the reference's optimizer (models/model_wrappers.py:40-41,124: Adam, lr 1e-3, weight_decay 1e-4)
@@ -247,7 +250,7 @@ def main():
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda"):
-            out = (model if split else net)(x)  # splitgraph: the buffer broadcast is issued outside the graph
+            out = (model if (split or evg) else net)(x)  # split / event graphs: the buffer broadcast stays outside
             loss = crit(out, t)
         scaler.scale(loss).backward()  # HipDDP hooks: per-bucket all-reduce on the comm stream, joined at the end
         if split:
@@ -259,9 +262,13 @@ def main():
         scaler.update()
 
     def step():
+        if evg:
+            net.broadcast_buffers_now()
         loss = fwd_bwd()
         if split:
             net.allreduce_packed()
+        elif evg:
+            net.allreduce_on_events()  # comm stream: wait(bucket event) -> all-reduce, per bucket; then joined
         opt_step()
         return loss
 
@@ -271,7 +278,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def all_agree(ok):
+    def all_agree(ok, over_rccl=False):
+        if over_rccl and ddp:  # (no collective was captured: the RCCL group itself can carry the vote)
+            f = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item())
         if ctl is None:
             return ok
         f = torch.tensor([1 if ok else 0])
@@ -294,7 +305,30 @@ def main():
         if ddp:
             HipDDP.quiesce_before_capture()  # let the RCCL watchdog retire the eager warm-up collectives first
         run = None
-        if not split:
+        if evg:
+            err = None
+            try:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=main_stream):
+                    static_loss = fwd_bwd()  # the hooks add one external event-record node per bucket
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream):
+                    opt_step()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            if all_agree(err is None, over_rccl=True):
+                def run():
+                    net.broadcast_buffers_now()
+                    ga.replay()
+                    net.allreduce_on_events()
+                    gb.replay()
+                    return static_loss
+            else:
+                print(f"[rank {rank}] event-graph capture failed ({err!r}); falling back to the eager loop",
+                      file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                loop_used = "eager"
+                run = step
+        elif not split:
             # ONE hipGraph for the whole step.  N > 1: the hooks fire during capture, so each bucket's all-reduce is
             # captured on the comm stream as a forked branch that runs under the remaining backward kernels.
             err = None
@@ -356,7 +390,10 @@ def main():
                                                              "overlapped with backward)" if ddp else ")"),
                  "eager": "eager" + (" (bucketed RCCL all-reduce on a side stream from autograd hooks, overlapped "
                                      "with backward)" if ddp else ""),
-                 "splitgraph": "hipgraph(fwd+bwd+pack) + eager RCCL all-reduce (not overlapped) + hipgraph(optimizer)"}
+                 "splitgraph": "hipgraph(fwd+bwd+pack) + eager RCCL all-reduce (not overlapped) + hipgraph(optimizer)",
+                 "evgraph": "hipgraph(fwd+bwd, one external event-record node per gradient bucket) + eager bucketed RCCL "
+                            "all-reduce on a side stream behind those events (overlapped with the replayed backward) + "
+                            "hipgraph(optimizer)"}
 
     out = {
         "metric": "images/sec (whole node) U-Net 3x256x256 train step" if (args.model, args.size) == ("UNet", 256)

@@ -40,6 +40,10 @@ PROTOTYPES = {
     "hipseg_pack_desc_fill": (I, [P, I, P, P, P, I, I, I, I, I]),
     "hipseg_pack_batch": (I, [P, I, I, L, P]),
     "hipseg_conv_igemm": (I, [I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, P]),
+    "hipseg_event_create": (I, [ctypes.POINTER(c_void_p)]),
+    "hipseg_event_destroy": (I, [P]),
+    "hipseg_event_record_external": (I, [P, P]),
+    "hipseg_stream_wait_event": (I, [P, P]),
     "hipseg_conv_affine_relu": (I, [I, P, I, P, I, P, P, P, P, I, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
     "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),

@@ -27,7 +27,7 @@ def _aligned(n):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "offsets", "pending", "work", "arrived")
+    __slots__ = ("flat", "params", "views", "offsets", "pending", "work", "arrived", "ext_ev")
 
     def __init__(self, params, device):
         self.offsets, o = [], 0
@@ -40,6 +40,7 @@ class _Bucket:
         self.pending = len(params)
         self.arrived = [False] * len(params)
         self.work = None
+        self.ext_ev = None  # overlap="events": HIP event recorded (as a graph node under capture) when the bucket is complete
 
 
 class HipDDP(nn.Module):
@@ -52,6 +53,13 @@ class HipDDP(nn.Module):
                        the graph, joined at the end of backward).
         overlap=False: no hooks; the caller runs pack_gradients() / allreduce_packed() after backward
                        (split-graph form: fwd+bwd+pack in one graph, the collective eager, the optimiser in a second).
+        overlap="events": for a forward+backward that is REPLAYED as a hipGraph while the collectives stay eager RCCL
+                       calls: the hooks only record one HIP event per bucket at the point of backward where the
+                       bucket is complete -- under capture an EXTERNAL event-record node of the graph
+                       (hipseg_event_record_external) -- and the caller runs allreduce_on_events() right after launching
+                       the graph: the communication stream waits for each bucket's event and reduces it while the
+                       rest of the replayed backward is still executing.  Overlapped like overlap=True, host cost of a
+                       graph launch, and no RCCL call inside any capture.
         force_collectives : issue every collective even when the group has ONE rank (RCCL runs them as device-side
                        no-op/copies), so the whole hook -> bucket -> event -> side-stream all-reduce -> join path can
                        be rehearsed and tested on a single-GPU box.
@@ -109,6 +117,20 @@ class HipDDP(nn.Module):
                 if not b.is_floating_point():
                     dist.broadcast(b, 0, group=self.pg)
         self.overlap = overlap
+        self.events_mode = overlap == "events"
+        self._order_building, self._ready_order = [], []
+        if self.events_mode:
+            if not self.on_gpu:
+                raise RuntimeError('HipDDP(overlap="events") needs the HIP library and a GPU')
+            import ctypes
+
+            from . import _lib as L
+
+            self._L = L
+            for b in self.buckets:
+                h = ctypes.c_void_p()
+                L.event_create(ctypes.byref(h))
+                b.ext_ev = h.value
         self._params = params
         self._hook_handles = []
         if overlap:
@@ -195,6 +217,11 @@ class HipDDP(nn.Module):
             self._launch(b)
 
     def _launch(self, b):
+        if self.events_mode:  # mark the point; allreduce_on_events() issues the collective behind it
+            self._L.event_record_external(b.ext_ev, torch.cuda.current_stream(self.device).cuda_stream)
+            self._order_building.append(b)
+            self.stats["event_records"] = self.stats.get("event_records", 0) + 1
+            return
         self.stats["buckets_reduced"] += 1
         if self.on_gpu:
             ev = torch.cuda.Event()
@@ -227,6 +254,8 @@ class HipDDP(nn.Module):
                 b.work = None
             b.pending = len(b.params)
             b.arrived = [False] * len(b.params)
+        if self.events_mode:  # the order in which this backward completed its buckets (kept across graph replays)
+            self._ready_order, self._order_building = self._order_building, []
         self._cb_queued = False
 
     # ------------------------------------------------------------------ explicit (non-overlapped) reduction
@@ -255,6 +284,34 @@ class HipDDP(nn.Module):
                     dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
                     b.flat.div_(self.world)
         self.use_bucket_grads()
+
+    def allreduce_on_events(self):
+        """overlap="events": reduce every bucket of the backward just issued (eagerly, or by launching the captured
+        graph) on the communication stream, each behind its bucket-complete event, then make the current stream wait
+        for the communication stream.  Call it right after backward / graph.replay()."""
+        if not self.events_mode:
+            raise RuntimeError('allreduce_on_events() belongs to HipDDP(overlap="events")')
+        if not self.active or not self._ready_order:
+            return
+        comm = self.comm_stream
+        for b in self._ready_order:
+            self._L.stream_wait_event(comm.cuda_stream, b.ext_ev)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+            self.stats["buckets_reduced"] += 1
+            self.stats["comm_stream_collectives"] += 1
+        torch.cuda.current_stream(self.device).wait_stream(comm)
+
+    def __del__(self):
+        L = getattr(self, "_L", None)
+        if L is not None:
+            for b in getattr(self, "buckets", []):
+                if b.ext_ev:
+                    try:
+                        L.event_destroy(b.ext_ev)
+                    except Exception:  # noqa: BLE001  (interpreter shutdown)
+                        pass
+                    b.ext_ev = None
 
     def use_bucket_grads(self):
         had = getattr(self, "_had_grad", None)

@@ -289,6 +289,18 @@ int hipseg_augment(const float* images, const int64_t* masks, const float* extra
                    const float* params, const int* order, float* partial, float* out_images,
                    int64_t* out_masks, float* out_extra, int B, int H, int W, hipseg_stream_t stream);
 
+/* ---- stream / event plumbing of the data-parallel step --------------------------------------
+ * External event-record nodes inside a captured hipGraph: eager work on another stream (the RCCL bucket all-reduces of
+ * hipseg/ddp.py) starts when the replayed graph passes the point where the event was recorded during capture.
+ * hipseg_event_record_external: hipEventRecordWithFlags(hipEventRecordExternal) -- a graph node while `stream` is
+ *   capturing, a plain record otherwise.  hipseg_stream_wait_event: hipStreamWaitEvent.
+ * replaces: the autograd-hook -> NCCL stream hand-over inside torch's DistributedDataParallel reducer
+ *           (scripts/train_distributed.py:35), for a step that is replayed as a hipGraph. */
+int hipseg_event_create(void** event);
+int hipseg_event_destroy(void* event);
+int hipseg_event_record_external(void* event, hipseg_stream_t stream);
+int hipseg_stream_wait_event(hipseg_stream_t stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,82 @@ def case_overlapped_allreduce_captured_in_one_hipgraph(pg):
         assert torch.equal(a, b)
 
 
+def case_event_graph_eager_allreduce_behind_external_events(pg):
+    """the benchmarked N > 1 default (bench.py --loop evgraph): hipGraph(zero_grad + fwd + loss + scaled bwd) whose hooks
+    add ONE external event-record node per bucket, the bucket all-reduces issued EAGERLY on the communication stream
+    behind those events right after the graph launch, hipGraph(GradScaler + Adam).  Replays must track an eager DDP-free
+    twin bit for bit; a poisoned bucket proves that the optimizer graph really waits for the reduced values and that
+    the collectives really wait for the graph (the poison is overwritten by the replayed backward first)."""
+    from hipseg.ddp import HipDDP
+    from hipseg.optim import Adam
+    from models.losses import HybridLoss
+    from models.UNet import UNet
+
+    x, t = _data()
+    crit = HybridLoss()
+
+    def make():
+        torch.manual_seed(11)
+        m = UNet().cuda().train()
+        return m, Adam(m.parameters(), lr=1e-3, weight_decay=1e-4), torch.amp.GradScaler("cuda")
+
+    def fwd_bwd(net, opt, scaler):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda"):
+            loss = crit(net(x), t)
+        scaler.scale(loss).backward()
+        return loss
+
+    def opt_step(opt, scaler):
+        scaler.step(opt)
+        scaler.update()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m0, o0, sc0 = make()
+        ref_losses = []
+        for _ in range(7):
+            ref_losses.append(float(fwd_bwd(m0, o0, sc0)))
+            opt_step(o0, sc0)
+        m1, o1, sc1 = make()
+        ddp = HipDDP(m1, overlap="events", force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
+        nb = len(ddp.buckets)
+        assert nb >= 4 and all(b.ext_ev for b in ddp.buckets)
+        losses = []
+        for _ in range(3):  # eager warm-up through the same code path (plain event records)
+            ddp.broadcast_buffers_now()
+            losses.append(float(fwd_bwd(m1, o1, sc1)))
+            ddp.allreduce_on_events()
+            opt_step(o1, sc1)
+        assert ddp.stats["event_records"] == 3 * nb and ddp.stats["comm_stream_collectives"] == 3 * nb
+        assert ddp.stats["hook_copies"] == 0
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        c0 = ddp.stats["comm_stream_collectives"]
+        with torch.cuda.graph(ga, stream=s):
+            static_loss = fwd_bwd(m1, o1, sc1)
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=s):
+            opt_step(o1, sc1)
+        assert ddp.stats["event_records"] == 4 * nb            # one external record node per bucket in the graph
+        assert ddp.stats["comm_stream_collectives"] == c0      # and NO collective inside the capture
+        assert [b for b in ddp._ready_order] and len(ddp._ready_order) == nb
+        for it in range(4):
+            for b in ddp.buckets:
+                b.flat.fill_(float("nan"))  # stale / poisoned slots: the replayed backward must rewrite them first
+            ddp.broadcast_buffers_now()
+            ga.replay()
+            ddp.allreduce_on_events()
+            gb.replay()
+            losses.append(float(static_loss))
+        torch.cuda.synchronize()
+        assert ddp.stats["comm_stream_collectives"] == c0 + 4 * nb
+    torch.cuda.current_stream().wait_stream(s)
+    assert losses == ref_losses, (losses, ref_losses)
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
 def case_unused_parameters_are_zero_filled_not_stale(pg):
     """ClipUnet's bottleneck ConvBlock receives no gradient (its output is replaced by the fusion,
     models/CLIP_models.py:126): the partially filled bucket must reduce zeros in those slots and leave .grad None."""
@@ -172,6 +248,7 @@ def case_unused_parameters_are_zero_filled_not_stale(pg):
 
 CASES = {f.__name__[len("case_"):]: f for f in (case_hook_path_matches_plain_backward_bitwise,
                                                 case_overlapped_allreduce_captured_in_one_hipgraph,
+                                                case_event_graph_eager_allreduce_behind_external_events,
                                                 case_unused_parameters_are_zero_filled_not_stale)}
 
 
