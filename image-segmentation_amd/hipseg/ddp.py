@@ -147,7 +147,9 @@ class HipDDP(nn.Module):
 
     @staticmethod
     def quiesce_before_capture(seconds=0.3):
-        """Call before capturing a step that contains collectives into a hipGraph.  torch's ProcessGroupNCCL watchdog
+        """Call before ANY hipGraph capture in a process that has issued eager collectives (with or without collectives
+        inside the capture: an intermittent capture failure of the event-graph test traced back to a missing call).
+        torch's ProcessGroupNCCL watchdog
         thread polls the end events of the EAGER collectives issued so far (warm-up steps) until it has seen them
         complete; a capture pulls the process group's internal RCCL stream into capture mode, and HIP then refuses
         `hipEventQuery` on an event whose stream is capturing (hipErrorCapturedEvent) -- the watchdog aborts the

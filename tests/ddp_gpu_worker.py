@@ -174,7 +174,9 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
             opt_step(o1, sc1)
         assert ddp.stats["event_records"] == 3 * nb and ddp.stats["comm_stream_collectives"] == 3 * nb
         assert ddp.stats["hook_copies"] == 0
-        torch.cuda.synchronize()
+        # (the RCCL watchdog thread must have retired the eager warm-up collectives before ANY capture starts: its
+        # hipEventQuery during a global-mode capture invalidates the capture -- an intermittent HIP error without this)
+        HipDDP.quiesce_before_capture()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         c0 = ddp.stats["comm_stream_collectives"]
         with torch.cuda.graph(ga, stream=s):
@@ -184,16 +186,39 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
         assert ddp.stats["event_records"] == 4 * nb            # one external record node per bucket in the graph
         assert ddp.stats["comm_stream_collectives"] == c0      # and NO collective inside the capture
         assert [b for b in ddp._ready_order] and len(ddp._ready_order) == nb
-        for it in range(4):
-            for b in ddp.buckets:
-                b.flat.fill_(float("nan"))  # stale / poisoned slots: the replayed backward must rewrite them first
-            ddp.broadcast_buffers_now()
-            ga.replay()
-            ddp.allreduce_on_events()
-            gb.replay()
-            losses.append(float(static_loss))
+        # (with ONE rank the all-reduce is an identity, so a collective that ran too early would go unnoticed in the
+        # results: a spy snapshots every bucket on the communication stream immediately before its collective)
+        import torch.distributed as dist
+
+        real_all_reduce, snaps = dist.all_reduce, []
+
+        def spy(tensor, *a, **k):
+            snaps.append(tensor.clone())  # runs on the current (= communication) stream, behind the bucket's event
+            return real_all_reduce(tensor, *a, **k)
+
+        dist.all_reduce = spy
+        try:
+            for it in range(4):
+                for b in ddp.buckets:
+                    b.flat.fill_(float("nan"))  # poisoned slots: the replayed backward must have rewritten them by then
+                ddp.broadcast_buffers_now()
+                ga.replay()
+                ddp.allreduce_on_events()
+                gb.replay()
+                losses.append(float(static_loss))
+        finally:
+            dist.all_reduce = real_all_reduce
         torch.cuda.synchronize()
         assert ddp.stats["comm_stream_collectives"] == c0 + 4 * nb
+        # 4 replays x nb buckets (+ 4 buffer broadcasts are not all_reduce): no snapshot may hold poison -- every
+        # collective really waited for the point of the REPLAYED backward where its bucket was complete
+        assert len(snaps) == 4 * nb
+        by_size = {b.flat.numel(): b for b in ddp.buckets}
+        assert len(by_size) == nb  # (bucket sizes are distinct here: a snapshot finds its bucket by length)
+        for c in snaps:
+            b = by_size[c.numel()]
+            for o, p in zip(b.offsets, b.params):  # (alignment padding between slots is never written: skip it)
+                assert bool(torch.isfinite(c[o:o + p.numel()]).all()), "a collective ran before its bucket was complete"
     torch.cuda.current_stream().wait_stream(s)
     assert losses == ref_losses, (losses, ref_losses)
     for a, b in zip(m0.parameters(), m1.parameters()):
