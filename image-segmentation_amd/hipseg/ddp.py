@@ -293,7 +293,7 @@ class HipDDP(nn.Module):
         for the communication stream.  Call it right after backward / graph.replay()."""
         if not self.events_mode:
             raise RuntimeError('allreduce_on_events() belongs to HipDDP(overlap="events")')
-        if not self.active or not self._ready_order:
+        if not self.active or not self._ready_order or not self._require_sync:  # (inside no_sync(): nothing to reduce)
             return
         comm = self.comm_stream
         for b in self._ready_order:
