@@ -305,13 +305,18 @@ def main():
         if ddp:
             HipDDP.quiesce_before_capture()  # let the RCCL watchdog retire the eager warm-up collectives first
         run = None
+        # with a process group alive, other threads of this process (torch's RCCL watchdog, RCCL's own helpers) may call
+        # the HIP runtime while we capture: "thread_local" keeps their calls from invalidating the capture (the default
+        # "global" mode did exactly that once, see HipDDP.quiesce_before_capture); kernels launched by the autograd
+        # thread on the capturing stream are captured in either mode
+        gmode = {"capture_error_mode": "thread_local"} if ddp else {}
         if evg:
             err = None
             try:
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=main_stream):
+                with torch.cuda.graph(ga, stream=main_stream, **gmode):
                     static_loss = fwd_bwd()  # the hooks add one external event-record node per bucket
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream):
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream, **gmode):
                     opt_step()
             except Exception as e:  # noqa: BLE001
                 err = e
@@ -334,7 +339,7 @@ def main():
             err = None
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=main_stream):
+                with torch.cuda.graph(graph, stream=main_stream, **gmode):
                     static_loss = step()
             except Exception as e:  # noqa: BLE001
                 if not ddp:
@@ -352,10 +357,10 @@ def main():
                 run = step
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=main_stream):
+            with torch.cuda.graph(ga, stream=main_stream, **gmode):
                 static_loss = fwd_bwd()
             net.use_bucket_grads()
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream, **gmode):
                 opt_step()
 
             def run():
