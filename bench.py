@@ -6,9 +6,17 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With --gpus N > 1 and no WORLD_SIZE in the environment, this process only LAUNCHES: before any GPU call it starts
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` as a child (fresh rank processes), relays rank 0's
-JSON line and exits with the child's code.  Fewer than N visible devices, or WORLD_SIZE != N, is an error.
+Process structure.  The process the driver (or torchrun) starts is a SUPERVISOR: it never touches the GPU.  Each
+supervisor (one per rank) runs the real benchmark as a WORKER child process (`HIPSEG_BENCH_WORKER=1`, fresh process) under
+a wall-clock limit and walks a LADDER of step loops -- N > 1: evgraph -> eager -> splitgraph; N = 1: graph -> eager --
+moving to the next loop when the worker exits non-zero (capture failed on some rank, replicas out of sync, RCCL abort)
+or exceeds the limit (a cross-rank ordering mismatch is a HANG, not an exception): the worker's process group is killed
+and a NEW worker is started on a fresh rendezvous port.  Rank 0's supervisor relays the worker's JSON line, with the
+loop actually used and, after a fall-back, `fallback_from` + the failed worker's stderr tail.  Workers themselves only
+ever exit; nothing is restarted in-process.
+With --gpus N > 1 and no WORLD_SIZE in the environment, the process first starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` as a child (whose ranks are supervisors as above)
+and exits with its code.  Fewer than N visible devices, or WORLD_SIZE != N, is an error (exit 2).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel (most device time) of the step -- achieved algorithmic
@@ -23,9 +31,11 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -157,6 +167,103 @@ def launch_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def ladder_for(loop, world, force_ddp=False):
+    """step loops to try, in order.  The first is the requested one (auto: evgraph with a process group, graph
+    without); the rest are the alternatives already in the tree, most overlapped first."""
+    ddp = world > 1 or force_ddp
+    first = ("evgraph" if ddp else "graph") if loop == "auto" else loop
+    if not ddp and first in ("splitgraph", "evgraph"):
+        first = "graph"
+    rest = ["evgraph", "eager", "splitgraph"] if ddp else ["graph", "eager"]
+    return [first] + [l for l in rest if l != first and not (first == "eager" and l == "evgraph")]
+
+
+def run_child(cmd, env, limit_s, stderr_path):
+    """run one worker in its own process group under a wall-clock limit.  Returns (rc, stdout text, timed_out); on a
+    timeout (or our own termination) the WHOLE process group of the worker is killed."""
+    with open(stderr_path, "wb") as ef:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=ef, start_new_session=True)
+        timed_out = False
+        try:
+            out, _ = p.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            out = b""
+        finally:
+            if p.poll() is None:
+                for sig in (signal.SIGTERM, signal.SIGKILL):
+                    try:
+                        os.killpg(p.pid, sig)
+                    except ProcessLookupError:
+                        break
+                    try:
+                        p.wait(timeout=10)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                try:
+                    out2, _ = p.communicate(timeout=5)
+                    out = out or out2
+                except Exception:  # noqa: BLE001
+                    pass
+    return (p.returncode if p.returncode is not None else -9), out.decode(errors="replace"), timed_out
+
+
+def _tail(path, n=1500):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            size = f.tell()
+            f.seek(max(0, size - n))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def supervise(args, world, start=run_child):
+    """the ladder (see the module docstring).  `start` is injectable for the CPU test of the ladder logic."""
+    rank = int(os.environ.get("RANK", "0"))
+    loops = ladder_for(args.loop, world, bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP")))
+    first_limit = float(os.environ.get("HIPSEG_BENCH_ATTEMPT_TIMEOUT", "420"))
+    base_port = int(os.environ.get("MASTER_PORT", "29533"))
+    argv = [a for i, a in enumerate(sys.argv[1:]) if a != "--loop" and (i == 0 or sys.argv[i] != "--loop")
+            and not a.startswith("--loop=")]
+    failures = []
+    tmp = tempfile.mkdtemp(prefix="hipseg_bench_")
+    for attempt, loop in enumerate(loops):
+        # a fresh rendezvous per attempt: rank 0's worker hosts a new TCPStore (a failed attempt leaves its keys --
+        # the RCCL unique id among them -- in the old one)
+        port = 1024 + (base_port - 1024 + 101 + 7 * attempt) % (65536 - 1024)
+        env = dict(os.environ, HIPSEG_BENCH_WORKER="1", HIPSEG_BENCH_ATTEMPT=str(attempt), MASTER_PORT=str(port),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), TORCHELASTIC_USE_AGENT_STORE="False",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--loop", loop]
+        errp = os.path.join(tmp, f"attempt{attempt}.stderr")
+        limit = first_limit if attempt == 0 else max(120.0, first_limit * 0.6)
+        t0 = time.time()
+        rc, out, timed_out = start(cmd, env, limit, errp)
+        sys.stderr.write(_tail(errp, 6000))
+        sys.stderr.flush()
+        line = next((l for l in reversed(out.splitlines()) if l.startswith("{") and l.rstrip().endswith("}")), None)
+        if rc == 0 and (rank != 0 or line is not None):
+            if rank == 0:
+                doc = json.loads(line)
+                if failures:
+                    doc["fallback_from"] = failures
+                doc["ladder"] = loops
+                print(json.dumps(doc), flush=True)
+            return 0
+        why = f"timed out after {limit:.0f} s" if timed_out else (f"exit code {rc}" if rc else "no JSON line")
+        failures.append({"loop": loop, "why": why, "seconds": round(time.time() - t0, 1), "rank": rank,
+                         "stderr_tail": _tail(errp, 1500)})
+        print(f"[bench supervisor rank {rank}] loop '{loop}' failed ({why}); "
+              + (f"starting fresh workers with '{loops[attempt + 1]}'" if attempt + 1 < len(loops) else "ladder exhausted"),
+              file=sys.stderr, flush=True)
+        if rc == 2 and not timed_out:  # configuration error (missing device, WORLD_SIZE mismatch): no loop can fix it
+            return 2
+    return 1
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -167,6 +274,12 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("HIPSEG_BENCH_WORKER") != "1":
+        sys.exit(supervise(args, world))
+    worker(args, world)
+
+
+def worker(args, world):
     # stdout carries exactly ONE line, the JSON: everything else that libraries print there while the benchmark runs
     # (RCCL writes its version banner to stdout when a communicator is created) is re-routed to stderr at the fd level
     sys.stdout.flush()

@@ -24,10 +24,16 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_args.h"
 
 #ifndef IGEMM_PPT
 #define IGEMM_PPT 1
 #endif
+
+// 16x16x32-MFMA kernel for the >= 128-channel 3x3 layers (conv3_m16.hip)
+int conv3_m16_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
+int conv3_m16_stats_rows(int rows, int B, int H, int W);
+int conv3_m16_launch(const ConvArgs& a, int rows, hipStream_t s);
 
 namespace {
 
@@ -63,31 +69,6 @@ struct Geo<HIPSEG_CONVT> {
     static constexpr int HH = TH, HW = TW, NT = 1;
 };
 
-struct ConvArgs {
-    const void* in0;
-    const void* in1;
-    const void* wp;
-    const float* bias;
-    const float* post_scale;  // inference epilogue (hipseg_conv_affine_relu): y = relu(conv * post_scale[n] + bias[n]),
-                              // `bias` then holds the folded shift; NULL = plain conv + bias
-    void* out0;
-    void* out1;
-    float* stats;
-    int C0, C1, N0, N1;
-    int B, H, W;    // GEMM-M pixel grid
-    int Hi, Wi;     // input spatial dims
-    int K, Kp, N, Np;
-    int tiles_x, tiles_y, ntn;
-    int vec_ok;
-    int ncu;      // compute units of the current device (grid of the persistent weights-stationary kernel)
-    int debug;  // ablation bits (HIPSEG_IGEMM_DEBUG): 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip epilogue
-    int xcd;    // XCD-aware workgroup order: 0 off, else grid / 8 (see xcd_block)
-};
-
-// Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Give every XCD a CONTIGUOUS run of
-// logical workgroup ids instead, so the N-tile workgroups of one pixel tile (same halo tile) and neighbouring
-// pixel tiles (shared halo rows) hit the same L2 (guide T1; needs grid % 8 == 0).
-__device__ __forceinline__ int xcd_block(int bid, int cpx) { return cpx ? (bid & 7) * cpx + (bid >> 3) : bid; }
 
 // Wave grid of a workgroup.  The generic kernel runs 4 waves; the DMA kernel runs 8 waves (two per SIMD, so
 // one wave's LDS / barrier waits hide behind the other's MFMAs) on the 256x128 tile.
@@ -1494,6 +1475,7 @@ extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return 4 * B * cdiv(H, 
 extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W) {
     const int g = wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W);
     if (g) return g * (N0 + N1 == 64 ? 2 : 4);  // one row per (workgroup, pixel-row wave group)
+    if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_stats_rows(r16, B, H, W);
     return hipseg_conv_mtiles(B, H, W);
 }
 
@@ -1550,6 +1532,9 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
+        if (!dbg || getenv("HIPSEG_M16_DEBUG")) {
+            if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_launch(a, r16, s);
+        }
         if (a.vec_ok && !no_dma && buf_ok) {
             // ConvTranspose2d forward / data gradient as a one-tap GEMM on pixel-major 64-channel stages
             static const bool no_g1 = getenv("HIPSEG_NO_GEMM1") != nullptr;  // A/B switch

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhipseg.so")
-SOURCES = ["pack.hip", "bn.hip", "pointwise.hip", "loss.hip", "records.hip", "augment.hip", "optim.hip", "sync.hip", "conv_igemm.hip", "conv_wgrad.hip"]
+SOURCES = ["pack.hip", "bn.hip", "pointwise.hip", "loss.hip", "records.hip", "augment.hip", "optim.hip", "sync.hip", "conv_igemm.hip", "conv3_m16.hip", "conv_wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 
@@ -28,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "hipseg.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_args.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "hipseg.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

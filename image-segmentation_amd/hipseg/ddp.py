@@ -14,6 +14,8 @@ dedicated stream that waits on an event recorded on the compute stream, so only 
 stem/enc1) bucket is exposed after backward.  One process per GPU; no data-path collective other
 than this all-reduce.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -41,6 +43,49 @@ class _Bucket:
         self.arrived = [False] * len(params)
         self.work = None
         self.ext_ev = None  # overlap="events": HIP event recorded (as a graph node under capture) when the bucket is complete
+
+
+class _HipEvents:
+    """overlap="events" on a GPU: HIP events; under capture the record is an EXTERNAL event-record graph node."""
+
+    def __init__(self):
+        from . import _lib as L
+
+        self._L = L
+
+    def create(self):
+        import ctypes
+
+        h = ctypes.c_void_p()
+        self._L.event_create(ctypes.byref(h))
+        return h.value
+
+    def record(self, ev, device):
+        self._L.event_record_external(ev, torch.cuda.current_stream(device).cuda_stream)
+
+    def wait(self, stream, ev):
+        self._L.stream_wait_event(stream.cuda_stream, ev)
+
+    def destroy(self, ev):
+        self._L.event_destroy(ev)
+
+
+class _HostEvents:
+    """overlap="events" without a GPU (gloo tests of the control flow): there is no asynchrony to order, so an event is
+    a token and record / wait do nothing -- allreduce_on_events() then runs the collectives synchronously, in the
+    order the buckets became ready."""
+
+    def create(self):
+        return object()
+
+    def record(self, ev, device):
+        pass
+
+    def wait(self, stream, ev):
+        pass
+
+    def destroy(self, ev):
+        pass
 
 
 class HipDDP(nn.Module):
@@ -119,18 +164,11 @@ class HipDDP(nn.Module):
         self.overlap = overlap
         self.events_mode = overlap == "events"
         self._order_building, self._ready_order = [], []
+        self._events = None
         if self.events_mode:
-            if not self.on_gpu:
-                raise RuntimeError('HipDDP(overlap="events") needs the HIP library and a GPU')
-            import ctypes
-
-            from . import _lib as L
-
-            self._L = L
+            self._events = _HipEvents() if self.on_gpu else _HostEvents()
             for b in self.buckets:
-                h = ctypes.c_void_p()
-                L.event_create(ctypes.byref(h))
-                b.ext_ev = h.value
+                b.ext_ev = self._events.create()
         self._params = params
         self._hook_handles = []
         if overlap:
@@ -138,28 +176,86 @@ class HipDDP(nn.Module):
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
         # gradient-as-bucket-view from the source: the HIP backward kernels write each parameter gradient straight into
         # its bucket slot (hipseg.ops.grad_out), so neither the hooks nor pack_gradients() move any data for them
+        # A slot is handed out at most ONCE per backward (`_taken`, cleared when a backward ends): a parameter that is
+        # used twice in one backward (a shared block, tied weights) gets a fresh tensor for its second partial gradient,
+        # so autograd sums two different buffers instead of two aliases of the same memory.
         self._slotted = []
+        self._taken = set()
         if self.on_gpu and grad_in_bucket:
             for b in self.buckets:
                 for p, o in zip(b.params, b.offsets):
-                    p._hipseg_slot = (b.flat, o)
+                    p._hipseg_slot = (b.flat, o, self._taken)
                     self._slotted.append(p)
+        self._graph_task = None
+
+    @staticmethod
+    def watchdog_idle(timeout=5.0):
+        """True once torch's ProcessGroupNCCL watchdog has RETIRED every collective it was handed (its work list is
+        empty), False if that did not happen within `timeout`, None when it cannot be observed.  Read from the
+        process group's flight recorder (`_dump_nccl_trace(onlyActive=True)` lists exactly the entries the watchdog
+        has not retired yet); needs TORCH_NCCL_TRACE_BUFFER_SIZE > 0 before the group is created
+        (`HipDDP.enable_watchdog_trace()`)."""
+        import pickle
+        import time
+
+        try:
+            from torch._C._distributed_c10d import _dump_nccl_trace
+        except ImportError:
+            return None
+        if int(os.environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "0") or 0) <= 0:
+            return None
+        deadline = time.monotonic() + timeout
+        while True:
+            try:
+                doc = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+            except Exception:  # noqa: BLE001  (signature / format drift: not observable)
+                return None
+            if not doc.get("entries"):
+                return True
+            if time.monotonic() > deadline:
+                return False
+            time.sleep(0.005)
+
+    @staticmethod
+    def enable_watchdog_trace():
+        """call BEFORE dist.init_process_group: turns on the flight recorder that watchdog_idle() reads."""
+        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")
 
     @staticmethod
     def quiesce_before_capture(seconds=0.3):
         """Call before ANY hipGraph capture in a process that has issued eager collectives (with or without collectives
-        inside the capture: an intermittent capture failure of the event-graph test traced back to a missing call).
-        torch's ProcessGroupNCCL watchdog
-        thread polls the end events of the EAGER collectives issued so far (warm-up steps) until it has seen them
-        complete; a capture pulls the process group's internal RCCL stream into capture mode, and HIP then refuses
-        `hipEventQuery` on an event whose stream is capturing (hipErrorCapturedEvent) -- the watchdog aborts the
-        process.  Draining the device and giving the watchdog (100 ms poll interval) time to retire its list removes
-        the race: collectives issued DURING capture are never handed to the watchdog."""
+        inside the capture).  torch's ProcessGroupNCCL watchdog thread polls the end events of the EAGER collectives
+        issued so far (warm-up steps) until it has seen them complete; a capture pulls the process group's internal RCCL
+        stream into capture mode, and HIP then refuses `hipEventQuery` on such an event ("HIP error: operation not
+        permitted on an event last recorded in a capturing stream", gpurun_out/a5/pytest.log of round 2) -- the watchdog
+        aborts the process; in the default global capture mode its query also invalidates the capture.
+        The fence is a CONDITION, not a delay: drain the device (every eager collective has completed), then wait until
+        the watchdog has retired every entry of its work list (watchdog_idle(): nothing left for it to query; collectives
+        issued DURING capture are never handed to it).  Only when the flight recorder is unavailable does it fall back
+        to sleeping `seconds` (three watchdog poll periods).  Returns how it fenced: "retired" / "sleep"."""
         import time
 
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        idle = HipDDP.watchdog_idle()
+        if idle:
+            return "retired"
         time.sleep(seconds)
+        return "sleep"
+
+    @staticmethod
+    def graph_capture(graph, stream=None, pool=None):
+        """THE capture recipe for a process with a live process group (bench.py and the tests use this one helper):
+        quiesce_before_capture(), then capture in "thread_local" error mode -- other threads of the process (torch's
+        RCCL watchdog, RCCL's own helpers) may call the HIP runtime while we capture without invalidating the capture;
+        kernels launched by the autograd thread on the capturing stream are captured in either mode."""
+        HipDDP.quiesce_before_capture()
+        kw = {"capture_error_mode": "thread_local"}
+        if stream is not None:
+            kw["stream"] = stream
+        if pool is not None:
+            kw["pool"] = pool
+        return torch.cuda.graph(graph, **kw)
 
     def remove_hooks(self):
         """detach this reducer from the module's parameters (before wrapping the same module again)."""
@@ -196,10 +292,36 @@ class HipDDP(nn.Module):
 
         return _Ctx()
 
+    def reset(self):
+        """Re-arm the per-backward state.  Autograd does not run the end-of-backward callback when backward RAISES (a
+        hook failing during a capture, an OOM): `_finalize` is then never called, the buckets stay half-counted and
+        `_cb_queued` stays set, so a later backward would never be reduced.  Call this after a failed backward / capture
+        before using the reducer again (the hooks also call it when they see a new backward with stale state)."""
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for b in self.buckets:
+            if b.work is not None and not self.on_gpu:
+                try:
+                    b.work.wait()
+                except Exception:  # noqa: BLE001
+                    pass
+            b.work = None
+            b.pending = len(b.params)
+            b.arrived = [False] * len(b.params)
+        self._order_building = []
+        self._cb_queued = False
+        self._taken.clear()
+        self.stats["resets"] = self.stats.get("resets", 0) + 1
+
     # ------------------------------------------------------------------ backward side
     def _hook(self, p):
         if not self._require_sync or not self.active:
             return
+        task = torch._C._current_graph_task_id()
+        if task != self._graph_task:  # first hook of a new backward
+            if self._cb_queued:  # ... but the previous one never reached _finalize (it raised): stale counters
+                self.reset()
+            self._graph_task = task
         self.stats["hook_calls"] += 1
         bi, pi = self._where[p]
         b = self.buckets[bi]
@@ -220,7 +342,7 @@ class HipDDP(nn.Module):
 
     def _launch(self, b):
         if self.events_mode:  # mark the point; allreduce_on_events() issues the collective behind it
-            self._L.event_record_external(b.ext_ev, torch.cuda.current_stream(self.device).cuda_stream)
+            self._events.record(b.ext_ev, self.device)
             self._order_building.append(b)
             self.stats["event_records"] = self.stats.get("event_records", 0) + 1
             return
@@ -259,11 +381,13 @@ class HipDDP(nn.Module):
         if self.events_mode:  # the order in which this backward completed its buckets (kept across graph replays)
             self._ready_order, self._order_building = self._order_building, []
         self._cb_queued = False
+        self._taken.clear()
 
     # ------------------------------------------------------------------ explicit (non-overlapped) reduction
     def pack_gradients(self):
         """copy every .grad into its flat bucket slot (multi-tensor copy: a few launches, capturable)."""
         views, grads = [], []
+        self._taken.clear()
         for b in self.buckets:
             for v, p in zip(b.views, b.params):
                 if p.grad is None:
@@ -297,20 +421,31 @@ class HipDDP(nn.Module):
             return
         comm = self.comm_stream
         for b in self._ready_order:
-            self._L.stream_wait_event(comm.cuda_stream, b.ext_ev)
-            with torch.cuda.stream(comm):
-                dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+            self._events.wait(comm, b.ext_ev)
+            if self.on_gpu:
+                with torch.cuda.stream(comm):
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+            else:  # gloo: no AVG op, no streams
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
+                b.flat.div_(self.world)
             self.stats["buckets_reduced"] += 1
             self.stats["comm_stream_collectives"] += 1
-        torch.cuda.current_stream(self.device).wait_stream(comm)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(comm)
+
+    def ready_order(self):
+        """bucket indices in the order the last backward completed them (overlap="events"); identical on every rank for
+        the same model -- the order in which allreduce_on_events() issues the collectives, which must agree across ranks
+        (as torch DDP's bucket order does, scripts/train_distributed.py:35)."""
+        return [next(i for i, x in enumerate(self.buckets) if x is b) for b in self._ready_order]
 
     def __del__(self):
-        L = getattr(self, "_L", None)
-        if L is not None:
+        ev = getattr(self, "_events", None)
+        if ev is not None:
             for b in getattr(self, "buckets", []):
                 if b.ext_ev:
                     try:
-                        L.event_destroy(b.ext_ev)
+                        ev.destroy(b.ext_ev)
                     except Exception:  # noqa: BLE001  (interpreter shutdown)
                         pass
                     b.ext_ev = None
@@ -332,6 +467,7 @@ class HipDDP(nn.Module):
 
     # ------------------------------------------------------------------ forward side
     def forward(self, *args, **kwargs):
+        self._taken.clear()  # (a new step; inside no_sync() no end-of-backward callback clears it)
         if self.module.training and torch.is_grad_enabled():
             self.broadcast_buffers_now()
         return self.module(*args, **kwargs)

@@ -93,14 +93,17 @@ def _f32(n, device):
 
 
 # ---- gradient destinations.  HipDDP attaches to each parameter the slot of its flat fp32 reduction bucket
-# (`p._hipseg_slot = (flat bucket, element offset)`); the backward kernels then write parameter gradients STRAIGHT into
+# (`p._hipseg_slot = (flat bucket, element offset, ids of the parameters whose slot this backward has handed out)`); the backward kernels then write parameter gradients STRAIGHT into
 # the bucket (a fresh view per backward, so autograd's AccumulateGrad adopts it without a copy) and the reducer's hooks
 # have nothing to move.  Parameters without a slot, or whose .grad is being accumulated into, get an ordinary new tensor.
 def grad_out(p):
     s = getattr(p, "_hipseg_slot", None)
     if s is None or p.grad is not None:
         return torch.empty(p.shape, dtype=torch.float32, device=p.device)
-    flat, o = s
+    flat, o, taken = s
+    if id(p) in taken:  # second use of the parameter in this backward: its slot already holds the first partial gradient
+        return torch.empty(p.shape, dtype=torch.float32, device=p.device)
+    taken.add(id(p))
     return flat[o:o + p.numel()].view(p.shape)
 
 
@@ -109,7 +112,10 @@ def grad_out_pair(first, second):
     adjacent in that order (BatchNorm bias, weight: the layout bn_bwd's [sum g, sum g*xhat] vector has), else new."""
     n1, n2 = first.numel(), second.numel()
     a, b = getattr(first, "_hipseg_slot", None), getattr(second, "_hipseg_slot", None)
-    if a is not None and b is not None and a[0] is b[0] and a[1] + n1 == b[1] and first.grad is None and second.grad is None:
+    if (a is not None and b is not None and a[0] is b[0] and a[1] + n1 == b[1] and first.grad is None
+            and second.grad is None and id(first) not in a[2] and id(second) not in a[2]):
+        a[2].add(id(first))
+        a[2].add(id(second))
         return a[0][a[1]:a[1] + n1 + n2]
     return torch.empty(n1 + n2, dtype=torch.float32, device=first.device)
 

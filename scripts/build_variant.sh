@@ -8,7 +8,7 @@ tag=$1; src=$2; shift 2
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value "$@" -c csrc/$base.hip -o hipseg/lib/${base}_$tag.o
 objs=""
-for o in pack bn pointwise loss records augment optim sync conv_igemm conv_wgrad; do
+for o in pack bn pointwise loss records augment optim sync conv_igemm conv3_m16 conv_wgrad; do
   if [ $o = $base ]; then objs="$objs hipseg/lib/${base}_$tag.o"; else objs="$objs hipseg/lib/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hipseg/lib/libhipseg_$tag.so $objs

@@ -10,8 +10,13 @@ from hipseg import _lib as L, ops
 
 LAYERS = [  # name, B, Cin, Cout, H
     ("enc1.c1", 16, 64, 64, 256), ("enc2.c0", 16, 64, 128, 128), ("enc2.c1", 16, 128, 128, 128),
-    ("enc3.c1", 16, 256, 256, 64), ("bott.c1", 16, 512, 512, 32), ("dec4.c1", 16, 32, 32, 256),
-    ("dec1.c0", 16, 512, 256, 32), ("dec1.c1", 16, 256, 256, 32), ("dec2.c1", 16, 128, 128, 64),
+    ("enc3.c0", 16, 128, 256, 64), ("enc3.c1", 16, 256, 256, 64), ("bott.c0", 16, 256, 512, 32),
+    ("bott.c1", 16, 512, 512, 32), ("dec4.c1", 16, 32, 32, 256),
+    ("dec1.c0", 16, 512, 256, 32), ("dec1.c1", 16, 256, 256, 32), ("dec2.c0", 16, 256, 128, 64),
+    ("dec2.c1", 16, 128, 128, 64),
+    # data gradients whose shape differs from a forward layer's (K = Cout, N = Cin)
+    ("enc3.c0^T", 16, 256, 128, 64), ("bott.c0^T", 16, 512, 256, 32), ("dec1.c0^T", 16, 256, 512, 32),
+    ("dec2.c0^T", 16, 128, 256, 64),
 ]
 which = sys.argv[1] if len(sys.argv) > 1 else "igemm"
 only = os.environ.get("MICRO_LAYERS")

@@ -219,6 +219,99 @@ for overlap in (True, False):
     assert torch.allclose(net4.b.bias.grad, torch.full((2,), 3.0)), net4.b.bias.grad
     assert torch.allclose(net4.a.bias.grad, (net4.b.weight.sum(0) * 3).detach())
     ddp4.remove_hooks()
+# ---- overlap="events" (what `bench.py --gpus N` runs by default): the control flow on CPU through the host event shim
+def mknet():
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1))
+torch.manual_seed(11)
+net5 = mknet()
+ddp5 = HipDDP(net5, overlap="events", bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+assert len(ddp5.buckets) >= 3
+for it in range(3):
+    ddp5.zero_grad(set_to_none=(it != 1))
+    ddp5(xs[rank]).square().mean().backward()
+    local = [p.grad.detach().clone() for p in net5.parameters()]       # hooks ran, nothing reduced yet
+    order = ddp5.ready_order()
+    assert sorted(order) == list(range(len(ddp5.buckets))), order
+    seen = [None] * world
+    dist.all_gather_object(seen, order)
+    assert all(o == order for o in seen), seen                         # identical collective order on every rank
+    before = ddp5.stats["buckets_reduced"]
+    ddp5.allreduce_on_events()
+    assert ddp5.stats["buckets_reduced"] - before == len(ddp5.buckets)
+    for p, g in zip(net5.parameters(), local):
+        ref = g.clone(); dist.all_reduce(ref); ref /= world
+        assert torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-8), it
+        assert any(p.grad.data_ptr() == v.data_ptr() for b in ddp5.buckets for v in b.views)
+# no_sync(): gradients stay local, nothing is reduced
+with ddp5.no_sync():
+    ddp5.zero_grad(set_to_none=True)
+    ddp5(xs[rank]).square().mean().backward()
+    before = ddp5.stats["buckets_reduced"]
+    ddp5.allreduce_on_events()
+    assert ddp5.stats["buckets_reduced"] == before
+# unused parameters in events mode: zero-filled slot, the bucket is still reduced, .grad stays None
+torch.manual_seed(5)
+net6 = Unused()
+ddp6 = HipDDP(net6, overlap="events", bucket_cap_mb=1.0, first_bucket_mb=1.0)
+ddp6.buckets[0].flat.fill_(123.0)
+ddp6(torch.full((3, 4), float(rank + 1))).sum().backward()
+ddp6.allreduce_on_events()
+assert net6.dead.weight.grad is None
+bi, pi = ddp6._where[net6.dead.weight]
+assert float(ddp6.buckets[bi].views[pi].abs().max()) == 0.0
+assert torch.allclose(net6.b.bias.grad, torch.full((2,), 3.0))
+ddp6.remove_hooks(); ddp5.remove_hooks()
+# ---- a backward that RAISES leaves no stale state behind (HipDDP.reset via the new-backward check in the hooks)
+for mode in (True, "events"):
+    torch.manual_seed(21)
+    net7 = mknet()
+    ddp7 = HipDDP(net7, overlap=mode, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+    fired = []
+    def boom(p):
+        if not fired:
+            fired.append(1)
+            raise RuntimeError("injected hook failure")
+    h = net7[0].weight.register_post_accumulate_grad_hook(boom)   # the LAST gradient of backward: buckets are in flight
+    try:
+        ddp7(xs[rank]).square().mean().backward()
+        raise SystemExit("the injected failure did not propagate")
+    except RuntimeError as e:
+        assert "injected" in str(e)
+    assert ddp7._cb_queued                                         # the end-of-backward callback never ran
+    ddp7.zero_grad(set_to_none=True)
+    ddp7(xs[rank]).square().mean().backward()
+    local = None
+    if mode == "events":
+        assert sorted(ddp7.ready_order()) == list(range(len(ddp7.buckets)))
+        ddp7.allreduce_on_events()
+    assert ddp7.stats.get("resets", 0) == 1 and not ddp7._cb_queued
+    net8 = mknet(); acc = None
+    for r in range(world):
+        net8.load_state_dict(net7.state_dict()); net8.train(); net8.zero_grad()
+        net8(xs[r]).square().mean().backward()
+        g = [p.grad.clone() for p in net8.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    for p, b in zip(net7.parameters(), acc):
+        assert torch.allclose(p.grad, b / world, rtol=1e-5, atol=1e-7), mode
+    h.remove(); ddp7.remove_hooks()
+# ---- a module applied twice in one backward: the sum of both partial gradients is what gets averaged
+class Twice(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.f = nn.Linear(4, 4); self.g = nn.Linear(4, 2)
+    def forward(self, x):
+        return self.g(self.f(torch.relu(self.f(x))))
+torch.manual_seed(9)
+net9 = Twice(); ddp9 = HipDDP(net9, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+xr = torch.arange(12.0).reshape(3, 4) / 10 + rank
+ddp9(xr).square().sum().backward()
+net10 = Twice(); net10.load_state_dict(net9.state_dict()); acc = None
+for r in range(world):
+    net10.zero_grad(); net10(torch.arange(12.0).reshape(3, 4) / 10 + r).square().sum().backward()
+    g = [p.grad.clone() for p in net10.parameters()]
+    acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+for p, b in zip(net9.parameters(), acc):
+    assert torch.allclose(p.grad, b / world, rtol=1e-5, atol=1e-6)
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 """

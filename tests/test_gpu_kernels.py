@@ -73,6 +73,13 @@ CONV_CASES = [
     (1, 64, 64, 128, 24, 40),
     (1, 96, 32, 160, 18, 30),
     (4, 128, 0, 128, 128, 128),
+    # N % 128 == 0 and K % 32 == 0: the 16x16x32-MFMA kernel (conv3_m16.hip) -- 16- and 8-row tiles, deep K, several
+    # channel tiles, dual source with dual destination in the data gradient, ragged borders, H smaller than a tile
+    (2, 256, 0, 256, 20, 36),
+    (1, 128, 128, 128, 33, 17),
+    (1, 512, 0, 512, 16, 16),
+    (2, 128, 0, 384, 16, 32),
+    (16, 32, 0, 128, 64, 64),
     # >= 1024 tiles of 8x16 pixels with <= 64 channels: the weights-stationary persistent kernel (all four
     # K/N shapes between fwd and dgrad, dual source / dual destination, ragged image borders)
     (2, 64, 0, 64, 256, 256),
