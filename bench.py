@@ -72,6 +72,7 @@ def parse():
                     help="hip: hipseg.optim.Adam (one HIP launch per step); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eager", action="store_true", help="skip the eager-loop sub-record (N = 1)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -99,9 +100,59 @@ def cpu_baseline(args):
     for _ in range(args.cpu_steps):
         tr.step(x, t)
     dt = (time.perf_counter() - t0) / args.cpu_steps
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.lower().startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": round(args.cpu_batch / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "threads": cores, "host_cpus_visible": avail,
             "sample": f"{args.cpu_steps} steps of batch {args.cpu_batch} x 3x{args.size}x{args.size} fp32 "
                       f"(oracle/torch_ref.OracleTrainer, torch {torch.__version__} CPU, {cores} threads), 1 warm-up"}
+
+
+def parity_record():
+    """Part of the cpu_baseline leg (the only place bench.py may call the oracle), OUTSIDE the timed region: one
+    2x3x64x64 UNet forward + CE on the HIP path, fp32 and bf16, against oracle/torch_ref.py on the same deterministic
+    weights and inputs.  Gates (north star): fp32 logits max-abs <= 1e-4; bf16 reported as mask agreement / mean IoU
+    (on this UNTRAINED near-tied fixture the reference's own CPU bf16 scores 0.94-0.98)."""
+    import torch
+
+    import hipseg
+    from models.losses import HybridLoss
+    from models.UNet import UNet
+    from oracle import fill, torch_ref as R
+
+    shape = (2, 3, 64, 64)
+    x = torch.from_numpy(fill.uniform("smoke.x", shape, 0.0, 1.0))
+    t = torch.from_numpy(fill.randint("smoke.t", (shape[0],) + shape[2:], 3))
+    sd = fill.fill_state_dict(R.make_state("UNet"))
+    with torch.no_grad():
+        ref = R.unet_forward(x, sd, "UNet", train=True)
+        ref_loss = float(R.hybrid_loss(ref, t))
+    m = UNet()
+    fill.fill_state_dict(m.state_dict())
+    m = m.cuda().train()
+    crit = HybridLoss()
+    with torch.no_grad():
+        with hipseg.precision_mode("fp32"):
+            lf = m(x.cuda())
+            loss_f = float(crit(lf, t.cuda()))
+        fill.fill_state_dict(m.state_dict())  # (running statistics back to the fixture's)
+        with torch.autocast("cuda"):
+            lb = m(x.cuda())
+    torch.cuda.synchronize()
+    err = float((lf.cpu() - ref).abs().max())
+    pa, pr = lb.argmax(1).cpu(), ref.argmax(1)
+    ious = []
+    for c in range(3):
+        u = int(((pa == c) | (pr == c)).sum())
+        if u:
+            ious.append(int(((pa == c) & (pr == c)).sum()) / u)
+    return {"fixture": "UNet 2x3x64x64, oracle.fill weights (untrained), train-mode BN",
+            "fp32_logits_max_abs": err, "fp32_gate_1e-4": err <= 1e-4, "fp32_loss_abs_err": abs(loss_f - ref_loss),
+            "bf16_mask_agreement": float((pa == pr).float().mean()), "bf16_mask_mean_iou": sum(ious) / max(1, len(ious))}
 
 
 def _config_index(args, world):
@@ -274,8 +325,14 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    if os.environ.get("HIPSEG_BENCH_WORKER") != "1":
+    # under a profiler that preloads a GPU tool library (rocprofv3) this process has ALREADY initialised the GPU before
+    # main() runs: starting a child from it is the forbidden exec-after-GPU-init, so the benchmark runs in-process
+    profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_SDK_TOOL_LIBRARIES")) \
+        or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if os.environ.get("HIPSEG_BENCH_WORKER") != "1" and not profiled:
         sys.exit(supervise(args, world))
+    if args.loop == "auto" or (args.loop in ("splitgraph", "evgraph") and not (world > 1 or os.environ.get("HIPSEG_BENCH_FORCE_DDP"))):
+        args.loop = ladder_for(args.loop, world, bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP")))[0]
     worker(args, world)
 
 
@@ -290,6 +347,12 @@ def worker(args, world):
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HIPSEG_BENCH_FAIL_LOOP") == args.loop:  # test hook of the supervisor's ladder
+        mode = os.environ.get("HIPSEG_BENCH_FAIL_MODE", "exit")
+        print(f"[rank {rank}] injected failure of loop '{args.loop}' ({mode})", file=sys.stderr, flush=True)
+        if mode == "hang":
+            time.sleep(3600)
+        sys.exit(3)
     # the data-parallel code path (HipDDP); HIPSEG_BENCH_FORCE_DDP=1 takes it with a 1-rank RCCL group and every
     # collective still issued, to rehearse hooks / buckets / side stream / in-graph capture on a single-GPU box
     force = bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP"))
@@ -305,7 +368,14 @@ def worker(args, world):
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
+        from datetime import timedelta
+
+        from hipseg.ddp import HipDDP as _H
+
+        _H.enable_watchdog_trace()  # lets quiesce_before_capture() SEE the watchdog's work list drain
+        # a collective mismatch between ranks must ABORT (non-zero exit -> the supervisor's next loop), not hang
+        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev,
+                                timeout=timedelta(seconds=float(os.environ.get("HIPSEG_BENCH_PG_TIMEOUT", "90"))))
         # host-side agreement between ranks (never on the data path) -- only the in-graph RCCL capture needs one (all
         # ranks must take the same fallback); the default N > 1 loop (eager) creates no second process group at all
         want_graph = args.loop == "graph"
@@ -320,6 +390,7 @@ def worker(args, world):
     from hipseg import ops
     from hipseg.ddp import HipDDP
     import models.UNet as un
+
     from models.losses import HybridLoss
 
     torch.manual_seed(0)
@@ -415,65 +486,67 @@ def worker(args, world):
                 net.broadcast_buffers_now()
             loss = step()
         torch.cuda.synchronize()
-        if ddp:
-            HipDDP.quiesce_before_capture()  # let the RCCL watchdog retire the eager warm-up collectives first
         run = None
-        # with a process group alive, other threads of this process (torch's RCCL watchdog, RCCL's own helpers) may call
-        # the HIP runtime while we capture: "thread_local" keeps their calls from invalidating the capture (the default
-        # "global" mode did exactly that once, see HipDDP.quiesce_before_capture); kernels launched by the autograd
-        # thread on the capturing stream are captured in either mode
-        gmode = {"capture_error_mode": "thread_local"} if ddp else {}
+
+        def capture(graph, pool=None):
+            # ONE capture recipe (HipDDP.graph_capture: observable watchdog drain + thread_local error mode), shared
+            # with tests/ddp_gpu_worker.py
+            if ddp:
+                return HipDDP.graph_capture(graph, stream=main_stream, pool=pool)
+            return torch.cuda.graph(graph, stream=main_stream, **({"pool": pool} if pool is not None else {}))
+
+        def give_up(what, err):
+            # no in-process fall-back: a failed capture leaves allocator / reducer state nobody should time.  Every
+            # rank learns of it (vote), every rank exits non-zero, the supervisors start fresh workers on the next loop
+            print(f"[rank {rank}] {what} failed ({err!r})", file=sys.stderr, flush=True)
+            if ddp:
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+            sys.exit(3)
+
         if evg:
             err = None
             try:
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=main_stream, **gmode):
+                with capture(ga):
                     static_loss = fwd_bwd()  # the hooks add one external event-record node per bucket
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream, **gmode):
+                with capture(gb, pool=ga.pool()):
                     opt_step()
             except Exception as e:  # noqa: BLE001
                 err = e
-            if all_agree(err is None, over_rccl=True):
-                def run():
-                    net.broadcast_buffers_now()
-                    ga.replay()
-                    net.allreduce_on_events()
-                    gb.replay()
-                    return static_loss
-            else:
-                print(f"[rank {rank}] event-graph capture failed ({err!r}); falling back to the eager loop",
-                      file=sys.stderr, flush=True)
-                torch.cuda.synchronize()
-                loop_used = "eager"
-                run = step
+            if not all_agree(err is None, over_rccl=True):
+                give_up("event-graph capture", err)
+
+            def run():
+                net.broadcast_buffers_now()
+                ga.replay()
+                net.allreduce_on_events()
+                gb.replay()
+                return static_loss
         elif not split:
             # ONE hipGraph for the whole step.  N > 1: the hooks fire during capture, so each bucket's all-reduce is
             # captured on the comm stream as a forked branch that runs under the remaining backward kernels.
             err = None
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=main_stream, **gmode):
+                with capture(graph):
                     static_loss = step()
             except Exception as e:  # noqa: BLE001
-                if not ddp:
-                    raise
                 err = e
-            if all_agree(err is None):
-                def run():
-                    graph.replay()
-                    return static_loss
-            else:
-                print(f"[rank {rank}] hipGraph capture with in-graph RCCL failed ({err!r}); falling back to the eager "
-                      "overlapped loop", file=sys.stderr, flush=True)
-                torch.cuda.synchronize()
-                loop_used = "eager"
-                run = step
+            if not all_agree(err is None):
+                give_up("hipGraph capture of the step", err)
+
+            def run():
+                graph.replay()
+                return static_loss
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=main_stream, **gmode):
+            with capture(ga):
                 static_loss = fwd_bwd()
             net.use_bucket_grads()
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=main_stream, **gmode):
+            with capture(gb, pool=ga.pool()):
                 opt_step()
 
             def run():
@@ -502,6 +575,23 @@ def worker(args, world):
         elapsed = float(tmax)
     final_loss = float(loss.detach())
     ms = elapsed / args.steps * 1e3
+    # every rank applied the same averaged gradients to the same initial weights: the replicas must be BIT-identical.
+    # A reduction that ran before backward had written a bucket, or a wrong average, shows up here -- and the worker
+    # then exits non-zero (the supervisor tries the next loop) instead of reporting images/s of diverged replicas.
+    ranks_in_sync = None
+    if ddp:
+        with torch.no_grad():
+            cks = torch.stack([q.detach().double().sum() for q in trainable]
+                              + [torch.stack([q.detach().double().abs().sum() for q in trainable]).sum()])
+        lo, hi = cks.clone(), cks.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(cks).all())
+        if not ranks_in_sync:  # (every rank sees the same lo / hi: all of them leave)
+            print(f"[rank {rank}] replicas OUT OF SYNC after {args.steps} steps of loop '{loop_used}' "
+                  f"(max |hi - lo| = {float((hi - lo).abs().max()):.3e})", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(4)
     value = args.batch * world * args.steps / elapsed
     ev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     loop_desc = {"graph": "hipgraph (one graph per step" + ("; bucketed RCCL all-reduces captured on a side stream, "
@@ -529,7 +619,8 @@ def worker(args, world):
                    "weights": "random init (nn default)", "final_loss": round(final_loss, 5)},
         "ms_per_step_event_median": round(ev_ms[len(ev_ms) // 2], 4),
         "distributed": {"initialized": bool(ddp), "world_size": dist.get_world_size() if ddp else 1,
-                        "backend": dist.get_backend() if ddp else None,
+                        "backend": dist.get_backend() if ddp else None, "ranks_in_sync": ranks_in_sync,
+                        "capture_fence": HipDDP.last_quiesce if ddp else None, "loop": loop_used, "attempt": int(os.environ.get("HIPSEG_BENCH_ATTEMPT", "0")),
                         "ddp": ({"buckets": len(net.buckets), "bucket_mb": [round(b.flat.numel() * 4 / 2 ** 20, 2)
                                                                            for b in net.buckets], **net.stats}
                                 if ddp else None)},
@@ -568,8 +659,32 @@ def worker(args, world):
         out["kernels"] = kern
         out["mfma_kernels_ms_per_step"] = round(sum(v[2] for v in agg.values()) / nprof, 4)
 
+    # ---- the loop the reference's UNCHANGED TrainingWrapper.train runs (models/model_wrappers.py:162-180): eager,
+    # one loss.item() per step.  ms/step of that and the host time Python needs to ISSUE one step (206 launches).
+    if world == 1 and not ddp and not args.no_eager:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        issue, t0 = [], time.perf_counter()
+        nst = 10
+        for _ in range(nst):
+            ti = time.perf_counter()
+            l_ = step()
+            issue.append(time.perf_counter() - ti)
+            l_.item()
+        tot = (time.perf_counter() - t0) / nst
+        issue.sort()
+        out["eager"] = {"ms_per_step": round(tot * 1e3, 4), "host_issue_ms_per_step": round(issue[nst // 2] * 1e3, 4),
+                        "steps": nst, "images_per_s": round(args.batch / tot, 1),
+                        "vs_graph": round(tot * 1e3 / ms, 4),
+                        "note": "eager loop with loss.item() per step, as model_wrappers.py:167-180"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
+        if args.model == "UNet":
+            try:
+                out["parity"] = parity_record()
+            except Exception as e:  # noqa: BLE001  (a report, not a gate of the benchmark run)
+                out["parity"] = {"error": repr(e)}
     if ddp:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,13 +24,30 @@
 #include "common.h"
 #include "conv_args.h"
 
+#ifdef M16_STAMP
+// diagnostic build only (scripts/build_variant.sh stamp conv3_m16.hip -DM16_STAMP): per-workgroup s_memtime /
+// s_memrealtime stamps into a buffer nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6)
+__device__ unsigned long long g_m16_stamp[16384 * 8];
+extern "C" int hipseg_debug_m16_stamps(void* host, int nwg) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_m16_stamp), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#define STAMP(i) do { if (tid == 0 && blockIdx.x < 16384) g_m16_stamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_RT(i) do { if (tid == 0 && blockIdx.x < 16384) g_m16_stamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i)
+#define STAMP_RT(i)
+#endif
+
 namespace {
 
 template <int THT>
 struct M16Geo {
     static constexpr int NW = 4, BN = 128, KS = 32, SO = 4, NT = 9;
-    static constexpr int D = 2;   // weight fragments are loaded D taps ahead
-    static constexpr int PF = 6;  // activation fragments in flight (ds_read_b128 issued PF pixel blocks ahead)
+#ifndef M16_PF
+#define M16_PF 6
+#endif
+    static constexpr int D = 2;        // weight fragments are loaded D taps ahead
+    static constexpr int PF = M16_PF;  // activation fragments in flight (ds_read_b128 issued PF pixel blocks ahead)
     static constexpr int HW = 16 + 2, HH = THT + 2, NPIX = HH * HW;
     static constexpr int NGRP = (NPIX + 63) / 64, NPIXA = NGRP * 64;  // 64-pixel DMA groups of the halo tile
     static constexpr int A_BYTES = SO * NPIXA * 16, NSLOT = 3;
@@ -47,15 +64,16 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     typedef M16Geo<THT> G;
     typedef bf16 T;
-    constexpr int NT = G::NT, D = G::D, PF = G::PF, HW = G::HW, NPIX = G::NPIX, NPIXA = G::NPIXA, NPW = G::NPW;
-    constexpr int A_BYTES = G::A_BYTES;
+    constexpr int NT = G::NT, D = G::D, PF = G::PF, HW = G::HW, NPIX = G::NPIX, NPIXA = G::NPIXA, NGRP = G::NGRP;
+    constexpr int A_BYTES = G::A_BYTES, NPW = G::NPW;
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef int v4i __attribute__((ext_vector_type(4)));
     constexpr unsigned OOB_LANE = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
+    STAMP(0);
+    STAMP_RT(1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;  // MFMA row/column index and k-octet (operands) / row quad (results)
     const int bid = xcd_block(blockIdx.x, p.xcd);
@@ -64,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
     const int ty = (mtile / p.tiles_x) % p.tiles_y;
     const int img = mtile / (p.tiles_x * p.tiles_y);
     const int y0 = ty * THT, x0 = tx * 16, nw = ntile * G::BN + wave * 32;
+    const int nst = p.Kp / G::KS;
 
     const unsigned bytes0 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C0 * sizeof(T));
     const unsigned bytes1 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C1 * sizeof(T));
@@ -73,30 +92,39 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.wp), 0, (int)((size_t)NT * p.Kp * p.Np * sizeof(T)), 0x00020000);
 
-    // ---- activations: piece j of this wave = octet `wave` of halo pixels 64 j .. 64 j + 63 (1 KiB of the
-    // [octet][pixel][8] image).  Per-lane byte offsets against either source; border / padding pixels are out of range
-    // (the buffer bounds check writes zeros to LDS).
-    unsigned avo0[NPW], avo1[NPW];
+    // ---- activations: a piece = one octet of halo pixels 64 j .. 64 j + 63 (1 KiB of the [octet][pixel][8] image).
+    // Per-lane byte offsets against either source; border / padding pixels are out of range (the buffer bounds check
+    // writes zeros to LDS).  Wave w stages octet w of every group.
+    unsigned avo0[NGRP], avo1[NGRP];
+    const int my_oct = wave;
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
+    for (int j = 0; j < NGRP; ++j) {
         const int pix = j * 64 + lane, hy = pix / HW, hx = pix - hy * HW;
+#ifdef HIPSEG_ABLATE
+        // bit 16: every workgroup stages the halo tile of ONE of 8 tile positions (L2-resident activations)
+        const int ay0 = (p.debug & 16) ? 16 : y0, ax0 = (p.debug & 16) ? 16 * (blockIdx.x & 1) : x0;
+        const int aimg = (p.debug & 16) ? (blockIdx.x & 3) : img;
+        const int iy = ay0 - 1 + hy, ix = ax0 - 1 + hx;
+        const bool ok = pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const long apix = ((long)aimg * p.Hi + iy) * p.Wi + ix;
+#else
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = pix < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const long apix = ((long)img * p.Hi + iy) * p.Wi + ix;
-        avo0[j] = ok ? (unsigned)(apix * p.C0 * (long)sizeof(T) + wave * 16) : OOB_LANE;
-        avo1[j] = ok ? (unsigned)(apix * p.C1 * (long)sizeof(T) + wave * 16) : OOB_LANE;
+#endif
+        avo0[j] = ok ? (unsigned)(apix * p.C0 * (long)sizeof(T) + my_oct * 16) : OOB_LANE;
+        avo1[j] = ok ? (unsigned)(apix * p.C1 * (long)sizeof(T) + my_oct * 16) : OOB_LANE;
     }
-    const int nst = p.Kp / G::KS;
     // branch-free: the source tensor of a stage is a scalar select (a branch here also made the compiler's own vmcnt
     // bookkeeping for the weight loads pessimistic: it waited one tap early)
-    auto pieceA = [&](int slot, int stage, int j) {
+    auto pieceA = [&](int slot, int stage, int j, int oct) {
         const int c0 = stage * G::KS;
         bool live = stage < nst;  // pieces of stages past the end keep the VMEM count static: no lane fetches
 #ifdef HIPSEG_ABLATE
         live = live && !(p.debug & 1);
 #endif
         const bool second = c0 >= p.C0;
-        lds_void* dst = (lds_void*)(smem + slot * A_BYTES + (wave * NPIXA + j * 64) * 16);
+        lds_void* dst = (lds_void*)(smem + slot * A_BYTES + (oct * NPIXA + j * 64) * 16);
         const __amdgpu_buffer_rsrc_t r = second ? r_in1 : r_in0;
         const unsigned so = (unsigned)(second ? c0 - p.C0 : c0) * 2u;
         const unsigned vo = live ? (second ? avo1[j] : avo0[j]) : OOB_LANE;
@@ -123,6 +151,15 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             W[ring][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, wvo[j], so, 0));
     };
 
+    // epilogue constants, fetched before the main loop (a dependent global load at the head of the epilogue is exposed)
+    const int ch0 = nw + lg * 8;
+    float bv[8], sc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bv[k] = p.bias ? p.bias[ch0 + k] : 0.f;
+        sc[k] = AFF ? p.post_scale[ch0 + k] : 1.f;
+    }
+
     f32x4 acc[2][THT];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -134,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 
     // ---- prologue: stages 0 and 1, the weights of the first D taps
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) pieceA(0, 0, j);
+    for (int j = 0; j < NPW; ++j) pieceA(0, 0, j, wave);
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) pieceA(1, 1, j);
+    for (int j = 0; j < NPW; ++j) pieceA(1, 1, j, wave);
 #pragma unroll
     for (int t = 0; t < D; ++t) loadW(t, 0, t);
 
@@ -151,6 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D + 2 * NT + NPW) : "memory");
         __builtin_amdgcn_s_barrier();  // everyone's pieces of stage s landed; everyone left the slot stage s + 2 will fill
         __builtin_amdgcn_sched_barrier(0);
+#ifdef M16_STAMP
+        if (s == 0) STAMP(2);
+#endif
         const unsigned char* rd = smem + abase + slot * A_BYTES;
         const int nslot = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3
         const int wst = s + 1 < nst ? s + 1 : s;       // weights of the wrapped taps (clamped: a harmless re-read)
@@ -167,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
                 loadW((tap + D) % (D + 1), s, tap + D);
             else
                 loadW((tap + D) % (D + 1), wst, tap + D - NT);
-            if (tap < NPW) pieceA(nslot, s + 2, tap);
+            if (tap < NPW) pieceA(nslot, s + 2, tap, wave);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < THT; ++b) {
@@ -186,12 +226,12 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         slot = slot == 2 ? 0 : slot + 1;
     }
 
+    STAMP(3);
     // ---- epilogue, straight from the accumulators: lane (li, lg) holds pixel column li of every tile row b and
     // channels ch0 .. ch0 + 7 (block j, register e -> ch0 + 4 j + e)
 #ifdef HIPSEG_ABLATE
     if (p.debug & 8) return;
 #endif
-    const int ch0 = nw + lg * 8;
     T* dst;
     int stride;
     if (ch0 < p.N0) {
@@ -201,11 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         dst = reinterpret_cast<T*>(p.out1) + (ch0 - p.N0);
         stride = p.N1;
     }
-    float bv[8], sc[8], ssum[8], ssq[8];
+    float ssum[8], ssq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        bv[k] = p.bias ? p.bias[ch0 + k] : 0.f;
-        sc[k] = AFF ? p.post_scale[ch0 + k] : 1.f;
         ssum[k] = 0.f;
         ssq[k] = 0.f;
     }
@@ -247,6 +285,13 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             *reinterpret_cast<f32x4*>(row + p.N + 4) = f32x4{ssq[4], ssq[5], ssq[6], ssq[7]};
         }
     }
+#ifdef M16_STAMP
+    STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+    STAMP_RT(6);
+    if (tid == 0 && blockIdx.x < 16384) g_m16_stamp[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+#endif
 #else
     (void)p;
 #endif
@@ -260,12 +305,13 @@ int launch_m16(const ConvArgs& a0, hipStream_t s) {
     a.ntn = a.Np / G::BN;
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     a.xcd = (grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
+    const int threads = 256;
     if (a.post_scale) {
         if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, true>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a);
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, true>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     } else {
         if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, false>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, false>), dim3((unsigned)grid), dim3(256), G::LDS, s, a);
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, false>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     }
     HS_LAUNCH_CHECK("conv3_m16");
     return HIPSEG_OK;

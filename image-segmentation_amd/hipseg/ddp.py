@@ -89,6 +89,8 @@ class _HostEvents:
 
 
 class HipDDP(nn.Module):
+    last_quiesce = None  # how the most recent quiesce_before_capture() fenced ("retired" / "sleep")
+
     def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0,
                  broadcast_buffers=True, overlap=True, force_collectives=False, grad_in_bucket=True):
         """device_ids : accepted for call compatibility with `DDP(model, device_ids=[rank])`
@@ -238,10 +240,10 @@ class HipDDP(nn.Module):
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         idle = HipDDP.watchdog_idle()
-        if idle:
-            return "retired"
-        time.sleep(seconds)
-        return "sleep"
+        HipDDP.last_quiesce = "retired" if idle else "sleep"
+        if not idle:
+            time.sleep(seconds)
+        return HipDDP.last_quiesce
 
     @staticmethod
     def graph_capture(graph, stream=None, pool=None):

@@ -24,6 +24,8 @@ for c in $ctrs; do
   esac
 done
 cd /tmp && export TMPDIR=/tmp
+# bench.py as the WORKER itself: under rocprofv3 the supervisor must not spawn a child (the profiler has initialised the GPU)
+export HIPSEG_BENCH_WORKER=1
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 echo "rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 bench.py --no-cpu-baseline --no-roofline --loop eager --optimizer hip --steps 2 --warmup 1 $@" > $out/cmd.txt

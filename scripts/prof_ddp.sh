@@ -2,6 +2,8 @@
 # usage: scripts/prof_ddp.sh <tag>  -> kernel-trace stats of the 1-rank forced-DDP graph step vs the plain graph step
 tag=$1
 cd /tmp && export TMPDIR=/tmp
+# bench.py as the WORKER itself: under rocprofv3 the supervisor must not spawn a child (the profiler has initialised the GPU)
+export HIPSEG_BENCH_WORKER=1
 for mode in plain ddp; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_$mode
   mkdir -p $out

@@ -107,10 +107,10 @@ def case_overlapped_allreduce_captured_in_one_hipgraph(pg):
         m1, o1, sc1 = make()
         ddp = HipDDP(m1, force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
         losses = [float(train_step(ddp, o1, sc1)) for _ in range(3)]  # eager warm-up steps 0..2
-        HipDDP.quiesce_before_capture()  # (RCCL watchdog vs. capture: see its docstring)
         graph = torch.cuda.CUDAGraph()
         n0 = ddp.stats["comm_stream_collectives"]
-        with torch.cuda.graph(graph, stream=s):
+        # the ONE capture recipe bench.py uses too: observable watchdog drain + thread_local capture error mode
+        with HipDDP.graph_capture(graph, stream=s):
             static_loss = train_step(ddp, o1, sc1)
         assert ddp.stats["comm_stream_collectives"] - n0 == len(ddp.buckets)  # captured, not skipped
         # capture only records; replays are steps 3, 4, 5
@@ -175,13 +175,17 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
         assert ddp.stats["event_records"] == 3 * nb and ddp.stats["comm_stream_collectives"] == 3 * nb
         assert ddp.stats["hook_copies"] == 0
         # (the RCCL watchdog thread must have retired the eager warm-up collectives before ANY capture starts: its
-        # hipEventQuery during a global-mode capture invalidates the capture -- an intermittent HIP error without this)
-        HipDDP.quiesce_before_capture()
+        # hipEventQuery during a capture trips over events of the capturing stream.  HipDDP.graph_capture waits until
+        # the watchdog's work list is observably empty and captures in thread_local mode -- the recipe of bench.py)
+        how = HipDDP.quiesce_before_capture()
+        print("quiesce:", how, flush=True)
+        # ("retired": the flight recorder showed the watchdog's work list empty; "sleep": not observable on this build)
+        assert how in ("retired", "sleep")
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         c0 = ddp.stats["comm_stream_collectives"]
-        with torch.cuda.graph(ga, stream=s):
+        with HipDDP.graph_capture(ga, stream=s):
             static_loss = fwd_bwd(m1, o1, sc1)
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=s):
+        with HipDDP.graph_capture(gb, stream=s, pool=ga.pool()):
             opt_step(o1, sc1)
         assert ddp.stats["event_records"] == 4 * nb            # one external record node per bucket in the graph
         assert ddp.stats["comm_stream_collectives"] == c0      # and NO collective inside the capture
@@ -271,7 +275,69 @@ def case_unused_parameters_are_zero_filled_not_stale(pg):
         model.zero_grad(set_to_none=True)
 
 
+def case_block_applied_twice_and_failed_backward(pg):
+    """(a) a ConvBlock applied TWICE in one backward under HipDDP with gradients written straight into the bucket slots:
+    the slot is handed out once per backward, the second partial gradient gets its own tensor, autograd sums them
+    (before: both aliased the slot and the result was 2 x the last one).  (b) a backward that raises leaves no stale
+    reducer state: the next step equals the plain model's."""
+    import torch.nn as nn
+
+    from hipseg.ddp import HipDDP
+    from models.processing_blocks import ConvBlock
+
+    class Twice(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.block = ConvBlock(16, 16)
+            self.head = nn.Conv2d(16, 4, 1)
+
+        def forward(self, x):
+            return self.head(self.block(self.block(x)).float())
+
+    torch.manual_seed(4)
+    m = Twice().cuda().train()
+    x = torch.rand(2, 16, 16, 16, device="cuda")
+
+    def run(net):
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda"):
+            y = net(x)
+        y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in m.parameters()]
+
+    ref = run(m)
+    ddp = HipDDP(m, force_collectives=True, first_bucket_mb=0.001, bucket_cap_mb=0.01)
+    for it in range(2):
+        got = run(ddp)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), f"iteration {it}: a parameter used twice got a wrong gradient under HipDDP"
+    # (b) injected failure in the LAST hook of backward, then a clean step
+    fired = []
+
+    def boom(p):
+        if not fired:
+            fired.append(1)
+            raise RuntimeError("injected hook failure")
+
+    h = m.block.conv[0].weight.register_post_accumulate_grad_hook(boom)
+    try:
+        run(ddp)
+        raise AssertionError("the injected failure did not propagate")
+    except RuntimeError as e:
+        assert "injected" in str(e)
+    torch.cuda.synchronize()
+    assert ddp._cb_queued
+    got = run(ddp)
+    assert ddp.stats.get("resets", 0) == 1 and not ddp._cb_queued
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    h.remove()
+    ddp.remove_hooks()
+
+
 CASES = {f.__name__[len("case_"):]: f for f in (case_hook_path_matches_plain_backward_bitwise,
+                                                case_block_applied_twice_and_failed_backward,
                                                 case_overlapped_allreduce_captured_in_one_hipgraph,
                                                 case_event_graph_eager_allreduce_behind_external_events,
                                                 case_unused_parameters_are_zero_filled_not_stale)}
@@ -284,6 +350,9 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29547")
     torch.cuda.set_device(0)
+    from hipseg.ddp import HipDDP as _H
+
+    _H.enable_watchdog_trace()
     dist.init_process_group("nccl", init_method="env://", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         CASES[name](dist)

@@ -3,6 +3,7 @@ include/hipseg.h declares, pure-host geometry functions answer sanely, argument 
 loudly, the drop-in modules keep the reference's state_dict layout, the product path refuses CPU
 tensors (no CPU fallback), and the N > 1 gradient reducer is correct under gloo with world_size 2."""
 import os
+import time
 import re
 import subprocess
 import sys
@@ -55,7 +56,11 @@ def test_host_geometry_functions(L):
     # rows actually written: the per-64-pixel grid, except for the persistent weights-stationary kernel
     # (bf16 3x3, <= 64 channels, >= 1024 tiles of 8x16 pixels): one row per (workgroup, wave row group)
     assert L.conv_stats_rows(L.F32, L.CONV3, 64, 0, 64, 0, 16, 256, 256) == L.conv_mtiles(16, 256, 256)
-    assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 128, 0, 16, 256, 256) == L.conv_mtiles(16, 256, 256)
+    # the 16x16x32-MFMA kernel (N % 128 == 0, K % 32 == 0): one row per workgroup tile -- 16 x 16 pixels when that
+    # gives every CU its two workgroups, else 8 x 16
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 128, 0, 16, 256, 256) == 16 * 16 * 16
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 512, 0, 512, 0, 16, 32, 32) == 16 * 2 * 4
+    assert L.conv_stats_rows(L.BF16, L.CONV3, 48, 0, 128, 0, 16, 256, 256) == L.conv_mtiles(16, 256, 256)  # K % 32 != 0
     assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 64, 0, 1, 32, 32) == L.conv_mtiles(1, 32, 32)
     assert L.conv_stats_rows(L.BF16, L.CONV3, 64, 0, 64, 0, 16, 256, 256) == 512 * 2
     assert L.conv_stats_rows(L.BF16, L.CONV3, 32, 32, 32, 0, 16, 256, 256) == 512 * 4
@@ -412,3 +417,102 @@ def test_augment_oracle_exact_parts():
     out2, om2, _ = A.augment(torch.full((B, 3, H, W), 0.25), msk, None, p, [3, 2, 1, 0])
     np.testing.assert_allclose(out2[1].numpy(), 0.25, atol=1e-6)
     assert set(om2.unique().tolist()) <= {0, 1, 2}
+
+
+# ----------------------------------------------------------------------------- bench.py supervisor (loop ladder)
+def _bench():
+    import importlib
+
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_ladder_order():
+    b = _bench()
+    assert b.ladder_for("auto", 8) == ["evgraph", "eager", "splitgraph"]
+    assert b.ladder_for("auto", 1) == ["graph", "eager"]
+    assert b.ladder_for("auto", 1, force_ddp=True) == ["evgraph", "eager", "splitgraph"]
+    assert b.ladder_for("eager", 2) == ["eager", "splitgraph"]
+    assert b.ladder_for("splitgraph", 1) == ["graph", "eager"]
+
+
+def test_bench_supervisor_walks_the_ladder_with_fake_workers(monkeypatch, capsys):
+    """a failing / hanging first loop makes the supervisor start fresh workers on the next loop with a NEW rendezvous
+    port; rank 0 relays the JSON line with `fallback_from` (scripts/train_distributed.py:13-23 is what a worker does)"""
+    import json
+
+    b = _bench()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--loop", "auto"])
+    args = b.parse()
+    calls = []
+
+    def fake(cmd, env, limit, errp):
+        calls.append((cmd, env["MASTER_PORT"], env["HIPSEG_BENCH_WORKER"], limit))
+        open(errp, "w").write("boom on rank 1\n")
+        loop = cmd[cmd.index("--loop") + 1]
+        if loop == "evgraph":
+            return -9, "", True           # hung: killed at the limit
+        if loop == "eager":
+            return 4, "", False           # replicas out of sync
+        return 0, "RCCL banner\n" + json.dumps({"metric": "m", "value": 1.0}) + "\n", False
+
+    assert b.supervise(args, 2, start=fake) == 0
+    doc = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert [f["loop"] for f in doc["fallback_from"]] == ["evgraph", "eager"]
+    assert "timed out" in doc["fallback_from"][0]["why"] and "exit code 4" in doc["fallback_from"][1]["why"]
+    assert "boom on rank 1" in doc["fallback_from"][0]["stderr_tail"]
+    assert doc["ladder"] == ["evgraph", "eager", "splitgraph"] and doc["value"] == 1.0
+    assert [c[0][c[0].index("--loop") + 1] for c in calls] == ["evgraph", "eager", "splitgraph"]
+    assert all(c[0].count("--loop") == 1 and "auto" not in c[0] for c in calls)     # the requested loop was replaced
+    assert len({c[1] for c in calls}) == 3 and all(c[2] == "1" for c in calls)      # a fresh port per attempt
+    # all loops failing -> non-zero, nothing on stdout; a configuration error (exit 2) ends the ladder at once
+    assert b.supervise(args, 2, start=lambda *a: (open(a[3], "w").close(), (1, "", False))[1]) == 1
+    assert capsys.readouterr().out.strip() == ""
+    n = []
+    assert b.supervise(args, 2, start=lambda *a: (n.append(1), open(a[3], "w").close(), (2, "", False))[2]) == 2
+    assert len(n) == 1
+
+
+def test_bench_run_child_kills_the_whole_process_group(tmp_path):
+    """a hung worker (and the helpers it spawned) is gone after the limit"""
+    b = _bench()
+    pidfile = tmp_path / "pids"
+    code = ("import os,subprocess,sys,time\n"
+            "c = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(300)'])\n"
+            f"open({str(pidfile)!r}, 'w').write(f'{{os.getpid()}} {{c.pid}}')\n"
+            "print('started', flush=True)\ntime.sleep(300)\n")
+    t0 = time.time()
+    rc, out, timed_out = b.run_child([sys.executable, "-c", code], dict(os.environ), 3.0, str(tmp_path / "err"))
+    assert timed_out and rc != 0 and time.time() - t0 < 30
+    for pid in map(int, pidfile.read_text().split()):
+        for _ in range(50):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.1)
+        else:
+            # (a zombie still answers kill(pid, 0): it must at least not be running)
+            state = open(f"/proc/{pid}/stat").read().split()[2]
+            assert state == "Z", f"process {pid} survived the limit (state {state})"
+    rc, out, timed_out = b.run_child([sys.executable, "-c", "print('x'); raise SystemExit(5)"], dict(os.environ), 30.0,
+                                     str(tmp_path / "err2"))
+    assert (rc, out.strip(), timed_out) == (5, "x", False)
+
+
+def test_bench_ladder_end_to_end_subprocess(tmp_path):
+    """real supervisor + real worker processes on this GPU-less box: the first loop fails by the env switch, the second
+    because there is no GPU -- the supervisor reports both and exits non-zero without a JSON line"""
+    env = dict(os.environ, HIPSEG_BENCH_FAIL_LOOP="graph", HIPSEG_BENCH_ATTEMPT_TIMEOUT="200")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=400)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: the second loop succeeded (covered by the -m gpu rehearsal)")
+    assert r.stdout.strip() == ""
+    assert "injected failure of loop 'graph'" in r.stderr and "loop 'graph' failed (exit code 3)" in r.stderr
+    assert "starting fresh workers with 'eager'" in r.stderr and "ladder exhausted" in r.stderr

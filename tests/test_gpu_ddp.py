@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = ["hook_path_matches_plain_backward_bitwise", "overlapped_allreduce_captured_in_one_hipgraph",
-         "unused_parameters_are_zero_filled_not_stale", "event_graph_eager_allreduce_behind_external_events"]
+         "unused_parameters_are_zero_filled_not_stale", "event_graph_eager_allreduce_behind_external_events",
+         "block_applied_twice_and_failed_backward"]
 
 
 @pytest.mark.parametrize("case", CASES)
