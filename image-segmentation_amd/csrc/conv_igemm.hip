@@ -1517,7 +1517,13 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
     a.ntn = a.Np / bn;
     const int vec = dtype == HIPSEG_BF16 ? 8 : 4;
     a.vec_ok = (C0 % vec == 0) && (C1 % vec == 0);
+    // ablation bits produce WRONG results by design: they exist only in ablation builds
+    // (scripts/build_variant.sh <tag> <file> -DHIPSEG_ABLATE), never in the shipped library
+#ifdef HIPSEG_ABLATE
     static const int dbg = getenv("HIPSEG_IGEMM_DEBUG") ? atoi(getenv("HIPSEG_IGEMM_DEBUG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     a.debug = dbg;
     a.ncu = device_cus();
     a.xcd = 0;
@@ -1532,7 +1538,7 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
-        if (!dbg || getenv("HIPSEG_M16_DEBUG")) {
+        {
             if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_launch(a, r16, s);
         }
         if (a.vec_ok && !no_dma && buf_ok) {

@@ -698,7 +698,11 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
     a.vec_ok_q = (CV % vec == 0);
     a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
+#ifdef HIPSEG_ABLATE  // ablation bits give wrong results by design: ablation builds only (scripts/build_variant.sh)
     static const int dbg = getenv("HIPSEG_WGRAD_DEBUG") ? atoi(getenv("HIPSEG_WGRAD_DEBUG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     a.debug = dbg;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     const int nwg = pl.S * pl.UT * pl.VT;
