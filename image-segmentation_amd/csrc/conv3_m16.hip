@@ -177,11 +177,6 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 #pragma unroll
     for (int t = 0; t < D; ++t) loadW(t, 0, t);
 
-#if defined(M16_PRIO)
-    // experiment: the two co-resident workgroups of a CU get different MFMA issue priority, so that one finishes its
-    // main loop early and its epilogue stores run under the other's MFMAs (role = dispatch pass within the XCD)
-    if (((blockIdx.x >> 3) / (p.ncu >> 3)) & 1) __builtin_amdgcn_s_setprio(M16_PRIO);
-#endif
     int slot = 0;
     for (int s = 0; s < nst; ++s) {
         // VMEM operations retire in issue order, so "this wave's pieces of stage s have landed" is a counted wait: the
@@ -231,9 +226,6 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         slot = slot == 2 ? 0 : slot + 1;
     }
 
-#if defined(M16_PRIO)
-    __builtin_amdgcn_s_setprio(0);
-#endif
     STAMP(3);
     // ---- epilogue, straight from the accumulators: lane (li, lg) holds pixel column li of every tile row b and
     // channels ch0 .. ch0 + 7 (block j, register e -> ch0 + 4 j + e)

@@ -512,6 +512,289 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 weight gradient, >= 64 channels on both sides (13 of the 16 launches of a U-Net step): v_mfma_f32_16x16x32_bf16
+// on operands that BOTH come out of pixel-major LDS images through ds_read_b64_tr_b16 -- at any pixel offset, so the
+// three kx fragments of a halo row are three reads instead of one read + VALU element shifts (162 VALU instructions
+// per tile in wgrad_dma_kernel, whose MFMA loop ran at 0.57 of the held clock with no operand traffic at all).
+//   G[tap][u][v] = sum_pixels P[pixel + tap][u] * Q[pixel][v]:  A operand = P (rows = 16 u channels), B operand = Q
+//   (columns = 16 v channels), K = 32 pixels = the two 16-pixel tile rows y, y + 1 (k octet g: pixels 4g .. 4g + 3 of
+//   row y, then of row y + 1 -- the order is free as long as both operands use it).
+// Workgroup = 64 u x 64 v x 9 taps, 8 waves = (2 x 2 blocks of 32 channels) x 2 pixel-row halves ("k-split", summed
+// through LDS once at the end); a wave owns 9 x 2 x 2 accumulator blocks (144 registers) and walks 4 row pairs per
+// 16 x 16 pixel tile: 18 P fragments + 2 Q fragments -> 36 MFMAs per pair.
+// LDS images keep the global [pixel][64 channels] order (every 1-KiB LDS-DMA piece = 8 pixels x 128 B contiguous);
+// the 32-byte channel slots of a pixel row are XOR-swizzled with (pixel >> 1) & 3, so that the 8 consecutive pixels a
+// 32-lane half of a transposed read touches land on 8 different 32-byte bank groups (conflict-free at every offset).
+// The swizzle is applied on the DMA's SOURCE side (LDS destinations stay linear); fragment addresses are 8 per-lane
+// bases (one per pixel phase) plus compile-time offsets: no address arithmetic in the loop.
+// LDS-DMA issued from inline assembly.  With the builtin, the compiler knows the instruction writes LDS and -- because
+// the transposed-read builtin carries no memory operand it could prove disjoint -- puts `s_waitcnt vmcnt(0)` in front
+// of EVERY following ds_read_b64_tr_b16: each piece then completes before the next fragment read, i.e. the "DMA" of
+// the next tile runs synchronously inside the current one (visible in the ISA of wgrad_dma_kernel: G..G..W[vmcnt(0)]r).
+// As opaque assembly the pieces stay in flight; their landing is awaited explicitly (counted / zero vmcnt + barrier).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+    return v4i_t{(int)(unsigned)p, (int)((unsigned)(p >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma_piece(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+#ifdef WG_STAMP
+// diagnostic build only: per-workgroup cycle sums of the tile loop's phases (wave 0), into a buffer nothing else reads
+__device__ unsigned long long g_wg_stamp[4096 * 8];
+extern "C" int hipseg_debug_wg_stamps(void* host, int nwg) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamp), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+struct Tr16Geo {
+    static constexpr int TH = 16, NW = 8, KH = 8, NT = 9;
+    static constexpr int PHW = TW + 2, NPP = (TH + 2) * PHW, NPQ = TH * TW;
+    static constexpr int NPC_P = (NPP + 7) / 8, NPC_Q = NPQ / 8;  // 1-KiB pieces (8 pixels x 128 B)
+    static constexpr int NPW_P = (NPC_P + NW - 1) / NW, NPW_Q = NPC_Q / NW, NPW = NPW_P + NPW_Q;
+    static constexpr int PP_BYTES = NPC_P * 1024, Q_BYTES = NPC_Q * 1024, BUF = PP_BYTES + Q_BYTES;
+    static constexpr size_t RED_BYTES = (size_t)4 * NT * 16 * 64 * 4;  // 4 parked accumulator sets
+    static constexpr size_t RING_BYTES = (size_t)2 * BUF + 1024;       // + 1-KiB sink for pad pieces
+    static constexpr size_t LDS = RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES;
+    static constexpr int PF = 3;  // P fragments in flight
+    static_assert(LDS <= 160 * 1024 && NPC_Q % NW == 0, "geometry");
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef Tr16Geo G;
+    constexpr int NT = 9, PHW = G::PHW, NPP = G::NPP, NW = G::NW, NPC_P = G::NPC_P, NPW_P = G::NPW_P, NPW_Q = G::NPW_Q;
+    constexpr int PP_BYTES = G::PP_BYTES, BUF = G::BUF, PF = G::PF;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wu = wave & 1, wv = (wave >> 1) & 1;
+    const int bid = xcd_block(blockIdx.x, a.xcd);
+    const int vt = bid % a.VT;
+    const int ut = (bid / a.VT) % a.UT;
+    const int s = bid / (a.VT * a.UT);
+    const int u0 = ut * 64, v0 = vt * 64;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;  // 1-KiB aligned (declaration): bits 5-6 are slot bits
+    const unsigned sink = lds0 + 2 * BUF;
+
+    // ---- staging (LDS-DMA through buffer addressing; an out-of-range per-lane offset zero-fills)
+    const bool second = u0 >= a.CU0;  // the 64-channel u tile lies inside ONE source tensor (launch condition)
+    const int cstrideP = (second ? a.CU1 : a.CU0) * 2, cstrideQ = a.CV * 2;
+    const v4i_t r_p = make_rsrc(second ? a.p1 : a.p0, (unsigned)((size_t)a.B * a.H * a.W * cstrideP));
+    const v4i_t r_q = make_rsrc(a.q, (unsigned)((size_t)a.B * a.H * a.W * cstrideQ));
+    const unsigned soP = (unsigned)(second ? u0 - a.CU0 : u0) * 2u, soQ = (unsigned)v0 * 2u;
+    // lane -> (pixel row of the piece, 16-byte slot); source slot = destination slot with its 32-byte index XOR-ed
+    const int prow = lane >> 3, slot = lane & 7;
+    const unsigned colsrc = (unsigned)((((slot >> 1) ^ ((prow >> 1) & 3)) << 1) | (slot & 1)) * 16u;
+    int p_yx[NPW_P];  // halo-relative pixel (dy | dx << 8) of this lane in each of the wave's P pieces
+#pragma unroll
+    for (int j = 0; j < NPW_P; ++j) {
+        const int hp = (j * NW + wave) * 8 + prow, dy = hp / PHW;
+        p_yx[j] = dy | ((hp - dy * PHW) << 8);
+    }
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int sx = a.S % a.tiles_x, sy = (a.S / a.tiles_x) % a.tiles_y, si = a.S / per_img;
+    int ntx = s % a.tiles_x, nty = (s / a.tiles_x) % a.tiles_y, nimg = s / per_img, ntile = s;  // staging cursor
+    auto advance = [&]() {
+        ntile += a.S;
+        ntx += sx;
+        const int cx = ntx >= a.tiles_x;
+        ntx -= cx ? a.tiles_x : 0;
+        nty += sy + cx;
+        const int cy = nty >= a.tiles_y;
+        nty -= cy ? a.tiles_y : 0;
+        nimg += si + cy;
+    };
+    // piece j (0 .. NPW - 1) of the tile under the staging cursor into ring slot `base` (absolute LDS byte address)
+    auto piece = [&](int j, unsigned base, int img, int y0, int x0, bool live) {
+        if (j < NPW_P) {
+            const int pc = j * NW + wave;
+            const bool real = (j + 1) * NW <= NPC_P || pc < NPC_P;  // wave-uniform
+            const int gy = y0 - 1 + (p_yx[j] & 0xff), gx = x0 - 1 + (p_yx[j] >> 8);
+            const bool ok = live && real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                            (NPP % 8 == 0 || pc * 8 + prow < NPP);
+            const unsigned vo = ok ? (unsigned)(((img * a.H + gy) * a.W + gx) * cstrideP) + colsrc : OOB;
+            dma_piece(r_p, real ? base + pc * 1024 : sink, vo, soP);
+        } else {
+            const int pc = (j - NPW_P) * NW + wave;
+            const int pix = pc * 8 + prow, gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            const bool ok = live && gy < a.H && gx < a.W;
+            const unsigned vo = ok ? (unsigned)(((img * a.H + gy) * a.W + gx) * cstrideQ) + colsrc : OOB;
+            dma_piece(r_q, base + PP_BYTES + pc * 1024, vo, soQ);
+        }
+    };
+
+    // ---- fragment addresses.  Transposed read: 16-lane group g = lane >> 4 is k octet g; its lane 4q + p addresses
+    // pixel (4g + q) of the fragment's tile row, channels 4p .. 4p + 3 of the 16-channel block.
+    // Addresses are kept as absolute 32-bit LDS addresses (the LDS base folded in ONCE: "smem + offset" inside the loop
+    // is an add of a link-time symbol that the compiler cannot fold and would keep a second copy of every base alive).
+    const int g4q = 4 * (lane >> 4) + ((lane & 15) >> 2), p4 = lane & 3;
+    // P: halo pixel hp = h0 + C, C = (2 rp + ky + j) * PHW + kx (compile time); swizzle phase depends on C & 7 only
+    // (u block 1 of the wave = the same address with bit 5 flipped: one v_xor instead of 8 more address registers)
+    const int h0 = kh * G::KH * PHW + g4q;
+    unsigned pb[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) pb[m] = lds0 + (unsigned)(h0 * 128 + (((wu * 2) ^ (((h0 + m) >> 1) & 3)) * 32) + p4 * 8);
+    // Q: pixel q = q0 + (2 rp + j) * 16: phase always that of q0
+    const int q0 = kh * G::KH * TW + g4q;
+    unsigned qb[2];
+#pragma unroll
+    for (int vb = 0; vb < 2; ++vb)
+        qb[vb] = lds0 + (unsigned)(PP_BYTES + q0 * 128 + (((wv * 2 + vb) ^ ((q0 >> 1) & 3)) * 32) + p4 * 8);
+
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: the first tile
+    {
+        const bool live = ntile < a.ntiles;
+#pragma unroll
+        for (int j = 0; j < G::NPW; ++j) piece(j, lds0, nimg, nty * G::TH, ntx * TW, live);
+        advance();
+    }
+    int cur = 0;
+#ifdef WG_STAMP
+    unsigned long long st_dma = 0, st_bar = 0, st_cmp = 0, st_n = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int tile = s; tile < a.ntiles; tile += a.S) {
+#ifdef WG_STAMP
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile have landed
+#ifdef WG_STAMP
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_barrier();                      // everyone's have; everyone left the other slot
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef WG_STAMP
+        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+#endif
+        const bool more = ntile < a.ntiles;
+        const unsigned nbase = lds0 + (cur ^ 1) * BUF;
+        const int ny0 = nty * G::TH, nx0 = ntx * TW, nimgc = nimg;
+        // (pb / qb carry the ring slot's offset: updated in place per tile)
+        auto readP = [&](int f) {  // fragment f = (row pair, tap, u block)
+            const int rp = f / 18, tap = (f % 18) >> 1, ub = f & 1;
+            const int C0 = (2 * rp + tap / 3) * PHW + tap % 3, C1 = C0 + PHW;
+            unsigned a0 = pb[C0 & 7], a1 = pb[C1 & 7];
+            if (ub) {  // (opaque to the optimiser: hoisted out of the tile loop these XORs cost 8 registers)
+                asm volatile("v_xor_b32 %0, 32, %1" : "=v"(a0) : "v"(a0));
+                asm volatile("v_xor_b32 %0, 32, %1" : "=v"(a1) : "v"(a1));
+            }
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)a0 + C0 * 16);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)a1 + C1 * 16);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto readQ = [&](int rp, int vb) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)qb[vb] + (2 * rp) * TW * 16);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)qb[vb] + (2 * rp + 1) * TW * 16);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 af[PF], bq[2][2];
+        bq[0][0] = readQ(0, 0);
+        bq[0][1] = readQ(0, 1);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) af[i] = readP(i);
+#pragma unroll
+        for (int f = 0; f < 72; ++f) {
+            const int rp = f / 18, tap = (f % 18) >> 1, ub = f & 1;
+            if (f % 18 == 8 && rp + 1 < 4) {  // next row pair's Q fragments
+                bq[(rp + 1) & 1][0] = readQ(rp + 1, 0);
+                bq[(rp + 1) & 1][1] = readQ(rp + 1, 1);
+            }
+            if (f % 6 == 0 && f / 6 < G::NPW) piece(f / 6, nbase, nimgc, ny0, nx0, more);
+#ifdef HIPSEG_ABLATE
+            if (!(a.debug & 4))
+#endif
+            {
+                acc[tap][ub][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[rp & 1][0], acc[tap][ub][0], 0, 0, 0);
+                acc[tap][ub][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[rp & 1][1], acc[tap][ub][1], 0, 0, 0);
+            }
+            if (f + PF < 72) af[f % PF] = readP(f + PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_assert(G::NPW <= 12, "all pieces of a tile are issued inside its fragment walk");
+#ifdef WG_STAMP
+        {
+            const unsigned long long td = __builtin_amdgcn_s_memtime();
+            st_dma += tb - ta;
+            st_bar += tc - tb;
+            st_cmp += td - tc;
+            st_n += 1;
+        }
+#endif
+        advance();
+        {  // fragment bases follow the ring slot (in place: no second set of address registers)
+            const unsigned d = cur ? (unsigned)-BUF : (unsigned)BUF;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pb[m] += d;
+            qb[0] += d;
+            qb[1] += d;
+        }
+        cur ^= 1;
+    }
+    // ---- k-split halves meet in LDS (the ring is idle now), the kh == 0 waves write the slab [S][9][CUp][CVp]:
+    // accumulator block (tap, ub, vb): lane holds column v = lane & 15, rows u = 4 (lane >> 4) + e
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)(wave & 3) * (NT * 4 * 64);
+    if (kh == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(t * 4 + i) * 64 + lane] = acc[t][i >> 1][i & 1];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const int vcol = lane & 15, ur = 4 * (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 o = red[(t * 4 + i) * 64 + lane];
+                const int ub = i >> 1, vb = i & 1;
+                const int u = u0 + wu * 32 + ub * 16 + ur, v = v0 + wv * 32 + vb * 16 + vcol;
+                float* dst = a.slabs + (((size_t)s * NT + t) * a.CUp + u) * a.CVp + v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(size_t)e * a.CVp] = acc[t][ub][vb][e] + o[e];
+            }
+    }
+#ifdef WG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_wg_stamp + blockIdx.x * 8;
+        o[0] = st_dma; o[1] = st_bar; o[2] = st_cmp; o[3] = st_n;
+        o[4] = __builtin_amdgcn_s_memtime() - st_t0;
+        o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        o[6] = st_r0;
+    }
+#endif
+#else
+    (void)a;
+#endif
+}
+
+int launch_tr16(const WgArgs& a, hipStream_t s) {
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel), (size_t)Tr16Geo::LDS)) return rc;
+    hipLaunchKernelGGL(wgrad3_tr16_kernel, dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), Tr16Geo::LDS, s, a);
+    HS_LAUNCH_CHECK("conv_wgrad_tr16");
+    return HIPSEG_OK;
+}
+
 template <int NT, int UB, int VB>
 int launch_dma(const WgArgs& a, hipStream_t s) {
     constexpr size_t lds = DmaGeo<NT, UB, VB>::LDS;
@@ -712,7 +995,13 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     const int rgrid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     for (int ab = 0; ab < 1; ++ab) {
         int rc;
-        if (dma)
+        static const bool no_tr16 = getenv("HIPSEG_NO_WGRAD_TR16") != nullptr;  // A/B switch
+        const bool tr16 = dma && !no_tr16 && !dbg && mode == HIPSEG_CONV3 && CU % 64 == 0 && CV % 64 == 0 &&
+                          (CU1 == 0 || CU0 % 64 == 0) &&
+                          (size_t)B * H * W * (size_t)(CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1)) * 2 <= ((size_t)1 << 30);
+        if (tr16)
+            rc = launch_tr16(a, s);
+        else if (dma)
             rc = pl.NT == 9 ? launch_dma_blocks<9>(a, UB, VB, s) : launch_dma_blocks<1>(a, UB, VB, s);
         else if (dtype == HIPSEG_BF16)
             rc = pl.NT == 9 ? launch<bf16, 9>(a, s) : launch<bf16, 1>(a, s);
