@@ -105,3 +105,31 @@ static __global__ __launch_bounds__(256) void colreduce_inplace_kernel(float* __
     if (sl == 0 && c < RC) part[(size_t)r0 * RC + c] = (float)((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]));
 }
 
+// ---------------------------------------------------------------- LDS-DMA from inline assembly
+// With the builtins the compiler's own wait-count insertion defeats the software pipelines (ROCm 7.2, found in the ISA):
+//   * after __builtin_amdgcn_global_load_lds (a FLAT-encoded instruction) every later wait on an LDS read becomes
+//     `s_waitcnt lgkmcnt(0)` -- counted waits are "invalid while a flat access is pending" -- so a fragment ring
+//     issued 2-3 steps ahead is drained at every use (conv3_wstat_kernel: one full LDS latency per 4 MFMAs);
+//   * the transposed-read builtin (ds_read_b64_tr_b16) carries no memory operand the compiler could prove disjoint
+//     from a pending LDS-DMA write, so it puts `s_waitcnt vmcnt(0)` in front of EVERY such read that follows a DMA
+//     piece: the "DMA" of the next tile then completes synchronously inside the current one (wgrad_dma_kernel).
+// As opaque assembly the pieces stay in flight and the compiler keeps counting its LDS reads; landing is awaited
+// explicitly (counted / zero vmcnt + barrier), as the kernels already did.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+    return v4i_t{(int)(unsigned)p, (int)((unsigned)(p >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma_piece(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+// per-lane 64-bit source pointer form (global_load_lds_dwordx4)
+__device__ __forceinline__ void dma_piece_ptr(const void* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(src) : "memory");
+}
+
+

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
                         !(DBG && (p.debug & 1));
         const int e = (img * p.H + y0 - 1) * p.W + x0 - 1 + poff[g];
         const T* src = ok ? src0 + (long)e * cs : zero;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + (oct * NG + g) * 1024), 16, 0, 0);
+        dma_piece_ptr(src, (unsigned)(uintptr_t)(lds_void*)(base + (oct * NG + g) * 1024));
     };
 
     // prologue: DIST tiles go out at once

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
             const int ub = (img * a.PH + ps * (y0 - HALO) + pa) * a.PW + ps * (x0 - HALO) + pb;  // wave-uniform
             const int e = ub + ps * (py * a.PW + px);
             const char* src = ok ? lbaseP + (long)e * strideP : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + pc * 1024 : sink), 16, 0, 0);
+            dma_piece_ptr(src, (unsigned)(uintptr_t)(lds_void*)(real ? base + pc * 1024 : sink));
         } else {
             const int pc = (j - NPW_P) * NW + wave;
             const bool real = (j - NPW_P + 1) * NW <= NPC_Q || pc < NPC_Q;  // wave-uniform
@@ -375,8 +375,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
             const bool ok = live && real && okcQ && gy < a.H && gx < a.W;
             const int e = (img * a.H + gy) * a.W + gx;
             const char* src = ok ? lbaseQ + (long)e * strideQ : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(real ? base + PP_BYTES + pc * 1024 : sink), 16, 0,
-                                             0);
+            dma_piece_ptr(src, (unsigned)(uintptr_t)(lds_void*)(real ? base + PP_BYTES + pc * 1024 : sink));
         }
     };
 
@@ -528,23 +527,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgArgs a) {
 // 32-lane half of a transposed read touches land on 8 different 32-byte bank groups (conflict-free at every offset).
 // The swizzle is applied on the DMA's SOURCE side (LDS destinations stay linear); fragment addresses are 8 per-lane
 // bases (one per pixel phase) plus compile-time offsets: no address arithmetic in the loop.
-// LDS-DMA issued from inline assembly.  With the builtin, the compiler knows the instruction writes LDS and -- because
-// the transposed-read builtin carries no memory operand it could prove disjoint -- puts `s_waitcnt vmcnt(0)` in front
-// of EVERY following ds_read_b64_tr_b16: each piece then completes before the next fragment read, i.e. the "DMA" of
-// the next tile runs synchronously inside the current one (visible in the ISA of wgrad_dma_kernel: G..G..W[vmcnt(0)]r).
-// As opaque assembly the pieces stay in flight; their landing is awaited explicitly (counted / zero vmcnt + barrier).
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
-    return v4i_t{(int)(unsigned)p, (int)((unsigned)(p >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ void dma_piece(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
-}
-
 #ifdef WG_STAMP
 // diagnostic build only: per-workgroup cycle sums of the tile loop's phases (wave 0), into a buffer nothing else reads
 __device__ unsigned long long g_wg_stamp[4096 * 8];
@@ -562,7 +544,7 @@ struct Tr16Geo {
     static constexpr size_t RED_BYTES = (size_t)4 * NT * 16 * 64 * 4;  // 4 parked accumulator sets
     static constexpr size_t RING_BYTES = (size_t)2 * BUF + 1024;       // + 1-KiB sink for pad pieces
     static constexpr size_t LDS = RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES;
-    static constexpr int PF = 3;  // P fragments in flight
+    static constexpr int PF = 3;  // P fragments in flight (each feeds 4 MFMAs = 64 cycles)
     static_assert(LDS <= 160 * 1024 && NPC_Q % NW == 0, "geometry");
 };
 
@@ -578,7 +560,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave >> 2, wu = wave & 1, wv = (wave >> 1) & 1;
+    const int kh = wave >> 2, wu = wave & 3;  // pixel-row half, 16-channel u block of the wave (all 64 v channels)
     const int bid = xcd_block(blockIdx.x, a.xcd);
     const int vt = bid % a.VT;
     const int ut = (bid / a.VT) % a.UT;
@@ -640,23 +622,23 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
     // is an add of a link-time symbol that the compiler cannot fold and would keep a second copy of every base alive).
     const int g4q = 4 * (lane >> 4) + ((lane & 15) >> 2), p4 = lane & 3;
     // P: halo pixel hp = h0 + C, C = (2 rp + ky + j) * PHW + kx (compile time); swizzle phase depends on C & 7 only
-    // (u block 1 of the wave = the same address with bit 5 flipped: one v_xor instead of 8 more address registers)
     const int h0 = kh * G::KH * PHW + g4q;
     unsigned pb[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) pb[m] = lds0 + (unsigned)(h0 * 128 + (((wu * 2) ^ (((h0 + m) >> 1) & 3)) * 32) + p4 * 8);
-    // Q: pixel q = q0 + (2 rp + j) * 16: phase always that of q0
+    for (int m = 0; m < 8; ++m) pb[m] = lds0 + (unsigned)(h0 * 128 + ((wu ^ (((h0 + m) >> 1) & 3)) * 32) + p4 * 8);
+    // Q: pixel q = q0 + (2 rp + j) * 16: phase always that of q0; the wave reads all four 16-channel v blocks
     const int q0 = kh * G::KH * TW + g4q;
-    unsigned qb[2];
+    unsigned qb[4];
 #pragma unroll
-    for (int vb = 0; vb < 2; ++vb)
-        qb[vb] = lds0 + (unsigned)(PP_BYTES + q0 * 128 + (((wv * 2 + vb) ^ ((q0 >> 1) & 3)) * 32) + p4 * 8);
+    for (int vb = 0; vb < 4; ++vb) qb[vb] = lds0 + (unsigned)(PP_BYTES + q0 * 128 + ((vb ^ ((q0 >> 1) & 3)) * 32) + p4 * 8);
 
-    f32x4 acc[NT][2][2];
+    // wave tile: 16 u x 64 v x 9 taps = 36 accumulator blocks.  A P fragment feeds 4 MFMAs (64 cycles), so PF = 3
+    // fragments in flight cover the LDS latency; per row pair 18 + 8 transposed reads for 36 MFMAs.
+    f32x4 acc[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // prologue: the first tile
     {
@@ -687,16 +669,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
         const unsigned nbase = lds0 + (cur ^ 1) * BUF;
         const int ny0 = nty * G::TH, nx0 = ntx * TW, nimgc = nimg;
         // (pb / qb carry the ring slot's offset: updated in place per tile)
-        auto readP = [&](int f) {  // fragment f = (row pair, tap, u block)
-            const int rp = f / 18, tap = (f % 18) >> 1, ub = f & 1;
+        auto readP = [&](int f) {  // fragment f = (row pair, tap)
+            const int rp = f / NT, tap = f % NT;
             const int C0 = (2 * rp + tap / 3) * PHW + tap % 3, C1 = C0 + PHW;
-            unsigned a0 = pb[C0 & 7], a1 = pb[C1 & 7];
-            if (ub) {  // (opaque to the optimiser: hoisted out of the tile loop these XORs cost 8 registers)
-                asm volatile("v_xor_b32 %0, 32, %1" : "=v"(a0) : "v"(a0));
-                asm volatile("v_xor_b32 %0, 32, %1" : "=v"(a1) : "v"(a1));
-            }
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)a0 + C0 * 16);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)a1 + C1 * 16);
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)pb[C0 & 7] + C0 * 16);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)pb[C1 & 7] + C1 * 16);
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
         auto readQ = [&](int rp, int vb) {
@@ -704,28 +681,52 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(uintptr_t)qb[vb] + (2 * rp + 1) * TW * 16);
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        bf16x8 af[PF], bq[2][2];
-        bq[0][0] = readQ(0, 0);
-        bq[0][1] = readQ(0, 1);
+        bf16x8 af[PF], bq[4];
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb) bq[vb] = readQ(0, vb);
 #pragma unroll
         for (int i = 0; i < PF; ++i) af[i] = readP(i);
 #pragma unroll
-        for (int f = 0; f < 72; ++f) {
-            const int rp = f / 18, tap = (f % 18) >> 1, ub = f & 1;
-            if (f % 18 == 8 && rp + 1 < 4) {  // next row pair's Q fragments
-                bq[(rp + 1) & 1][0] = readQ(rp + 1, 0);
-                bq[(rp + 1) & 1][1] = readQ(rp + 1, 1);
-            }
-            if (f % 6 == 0 && f / 6 < G::NPW) piece(f / 6, nbase, nimgc, ny0, nx0, more);
+        for (int rp = 0; rp < 4; ++rp) {
+#pragma unroll
+            for (int tap = 0; tap < NT - 2; ++tap) {
+                const int f = rp * NT + tap;
+                if (f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, nimgc, ny0, nx0, more);
 #ifdef HIPSEG_ABLATE
-            if (!(a.debug & 4))
+                if (!(a.debug & 4))
 #endif
-            {
-                acc[tap][ub][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[rp & 1][0], acc[tap][ub][0], 0, 0, 0);
-                acc[tap][ub][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[rp & 1][1], acc[tap][ub][1], 0, 0, 0);
+                {
+#pragma unroll
+                    for (int vb = 0; vb < 4; ++vb)
+                        acc[tap][vb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[vb], acc[tap][vb], 0, 0, 0);
+                }
+                if (f + PF < 4 * NT) af[f % PF] = readP(f + PF);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (f + PF < 72) af[f % PF] = readP(f + PF);
-            __builtin_amdgcn_sched_barrier(0);
+            // The Q fragments are single-buffered: the LAST TWO taps of a row pair run v-block-major, and each v block's
+            // fragment of the NEXT row pair is read as soon as its last MFMA has issued (>= 6 MFMAs = 96 cycles before
+            // its first use).
+            {
+                const int f = rp * NT + NT - 2;
+                if (f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, nimgc, ny0, nx0, more);
+                if ((f + 1) % 3 == 0 && (f + 1) / 3 < G::NPW) piece((f + 1) / 3, nbase, nimgc, ny0, nx0, more);
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb) {
+#ifdef HIPSEG_ABLATE
+                    if (!(a.debug & 4))
+#endif
+                    {
+                        acc[NT - 2][vb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f % PF], bq[vb], acc[NT - 2][vb], 0, 0, 0);
+                        acc[NT - 1][vb] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(f + 1) % PF], bq[vb], acc[NT - 1][vb], 0, 0, 0);
+                    }
+                    if (rp + 1 < 4) bq[vb] = readQ(rp + 1, vb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (f + PF < 4 * NT) af[f % PF] = readP(f + PF);
+                if (f + 1 + PF < 4 * NT) af[(f + 1) % PF] = readP(f + 1 + PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         static_assert(G::NPW <= 12, "all pieces of a tile are issued inside its fragment walk");
 #ifdef WG_STAMP
@@ -742,13 +743,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
             const unsigned d = cur ? (unsigned)-BUF : (unsigned)BUF;
 #pragma unroll
             for (int m = 0; m < 8; ++m) pb[m] += d;
-            qb[0] += d;
-            qb[1] += d;
+#pragma unroll
+            for (int vb = 0; vb < 4; ++vb) qb[vb] += d;
         }
         cur ^= 1;
     }
     // ---- k-split halves meet in LDS (the ring is idle now), the kh == 0 waves write the slab [S][9][CUp][CVp]:
-    // accumulator block (tap, ub, vb): lane holds column v = lane & 15, rows u = 4 (lane >> 4) + e
+    // accumulator block (tap, vb): lane holds column v = lane & 15, rows u = 4 (lane >> 4) + e
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)(wave & 3) * (NT * 4 * 64);
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[(t * 4 + i) * 64 + lane] = acc[t][i >> 1][i & 1];
+            for (int i = 0; i < 4; ++i) red[(t * 4 + i) * 64 + lane] = acc[t][i];
     }
     __syncthreads();
     if (kh == 0) {
@@ -764,13 +765,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 o = red[(t * 4 + i) * 64 + lane];
-                const int ub = i >> 1, vb = i & 1;
-                const int u = u0 + wu * 32 + ub * 16 + ur, v = v0 + wv * 32 + vb * 16 + vcol;
+            for (int vb = 0; vb < 4; ++vb) {
+                const f32x4 o = red[(t * 4 + vb) * 64 + lane];
+                const int u = u0 + wu * 16 + ur, v = v0 + vb * 16 + vcol;
                 float* dst = a.slabs + (((size_t)s * NT + t) * a.CUp + u) * a.CVp + v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(size_t)e * a.CVp] = acc[t][ub][vb][e] + o[e];
+                for (int e = 0; e < 4; ++e) dst[(size_t)e * a.CVp] = acc[t][vb][e] + o[e];
             }
     }
 #ifdef WG_STAMP

@@ -445,7 +445,38 @@ def gen_round2():
     print("losses_r2.npz", len(lo))
 
 
+def gen_round3():
+    """Round 3: the binary (1-channel) model step of scripts/prompt_train.py:58 -- the reference UNet(out_channels=1)
+    with nn.BCEWithLogitsLoss, the PINNABLE half of HybridLossBinary (models/losses.py:21,33; the Dice half is
+    segmentation_models_pytorch, absent)."""
+    out = {}
+    x = T("bin.x", (2, 3, 64, 64))
+    t = torch.from_numpy((fill.uniform("bin.t", (2, 64, 64), 0.0, 1.0) > 0.5).astype(np.float32))
+    m = UNet(out_channels=1)
+    fill.fill_state_dict(m.state_dict())
+    m.eval()
+    with torch.no_grad():
+        out["unet_bin/eval_logits"] = npy(m(x))
+    m.train()
+    logits = m(x)
+    loss = nn.BCEWithLogitsLoss()(logits, t.unsqueeze(1))  # (B,H,W) target -> unsqueeze, models/losses.py:30-31
+    loss.backward()
+    out["unet_bin/train_logits"] = npy(logits)
+    out["unet_bin/bce_loss"] = npy(loss)
+    for k, p in m.named_parameters():
+        g = p.grad
+        out[f"unet_bin/gradstat/{k}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()),
+                                                  float(g.double().pow(2).sum())])
+    for k in ("out.weight", "out.bias", "dec4.conv.conv.3.weight", "input.weight"):
+        out[f"unet_bin/grad/{k}"] = npy(dict(m.named_parameters())[k].grad)
+    np.savez_compressed(os.path.join(HERE, "models_r3.npz"), **out)
+    print("models_r3.npz", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        gen_round3()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "records":  # regenerate one fixture file only
         gen_records()
         sys.exit(0)
@@ -458,3 +489,4 @@ if __name__ == "__main__":
     gen_losses()
     gen_records()
     gen_round2()
+    gen_round3()
