@@ -569,20 +569,37 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;  // 1-KiB aligned (declaration): bits 5-6 are slot bits
     const unsigned sink = lds0 + 2 * BUF;
 
-    // ---- staging (LDS-DMA through buffer addressing; an out-of-range per-lane offset zero-fills)
+    // ---- staging (LDS-DMA through buffer addressing; an out-of-range per-lane offset zero-fills).  The main loop is
+    // bound by VECTOR INSTRUCTION ISSUE (a 16x16x32 MFMA leaves 8 of its 16 cycles to other vector instructions; two
+    // waves x (104 transposed reads + the DMA address arithmetic) per tile filled them): a piece therefore costs 3
+    // VALU instructions -- per-lane byte offsets relative to the tile are constants (whole tiles only: launch
+    // condition H % 16 == 0, W % 16 == 0), the tile's origin is a scalar offset, and a lane whose halo pixel falls
+    // outside the image is found by AND-ing its per-piece edge flags with the tile's edge mask.
     const bool second = u0 >= a.CU0;  // the 64-channel u tile lies inside ONE source tensor (launch condition)
     const int cstrideP = (second ? a.CU1 : a.CU0) * 2, cstrideQ = a.CV * 2;
-    const v4i_t r_p = make_rsrc(second ? a.p1 : a.p0, (unsigned)((size_t)a.B * a.H * a.W * cstrideP));
+    // (descriptor base moved back by one row + one pixel: per-lane offsets are then relative to the halo origin
+    //  (y0 - 1, x0 - 1) and non-negative, the tile offset is that of (y0, x0) and non-negative)
+    const unsigned biasP = (unsigned)((a.W + 1) * cstrideP);
+    const v4i_t r_p = make_rsrc(reinterpret_cast<const char*>(second ? a.p1 : a.p0) - biasP,
+                                (unsigned)((size_t)a.B * a.H * a.W * cstrideP) + biasP);
     const v4i_t r_q = make_rsrc(a.q, (unsigned)((size_t)a.B * a.H * a.W * cstrideQ));
     const unsigned soP = (unsigned)(second ? u0 - a.CU0 : u0) * 2u, soQ = (unsigned)v0 * 2u;
     // lane -> (pixel row of the piece, 16-byte slot); source slot = destination slot with its 32-byte index XOR-ed
     const int prow = lane >> 3, slot = lane & 7;
     const unsigned colsrc = (unsigned)((((slot >> 1) ^ ((prow >> 1) & 3)) << 1) | (slot & 1)) * 16u;
-    int p_yx[NPW_P];  // halo-relative pixel (dy | dx << 8) of this lane in each of the wave's P pieces
+    // 5 flags per P piece: halo pixel in the top / bottom halo row, left / right halo column, lane beyond the halo tile
+    unsigned pofs[NPW_P], qofs[NPW_Q], pflags = 0;
 #pragma unroll
     for (int j = 0; j < NPW_P; ++j) {
-        const int hp = (j * NW + wave) * 8 + prow, dy = hp / PHW;
-        p_yx[j] = dy | ((hp - dy * PHW) << 8);
+        const int hp = (j * NW + wave) * 8 + prow, dy = hp / PHW, dx = hp - dy * PHW;
+        pofs[j] = (unsigned)((dy * a.W + dx) * cstrideP) + colsrc;
+        const unsigned f = hp < NPP ? (unsigned)((dy == 0) | ((dy == G::TH + 1) << 1) | ((dx == 0) << 2) | ((dx == PHW - 1) << 3)) : 16u;
+        pflags |= f << (5 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < NPW_Q; ++j) {
+        const int pix = (j * NW + wave) * 8 + prow;
+        qofs[j] = (unsigned)(((pix >> 4) * a.W + (pix & 15)) * cstrideQ) + colsrc;
     }
     const int per_img = a.tiles_x * a.tiles_y;
     const int sx = a.S % a.tiles_x, sy = (a.S / a.tiles_x) % a.tiles_y, si = a.S / per_img;
@@ -597,22 +614,30 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
         nty -= cy ? a.tiles_y : 0;
         nimg += si + cy;
     };
-    // piece j (0 .. NPW - 1) of the tile under the staging cursor into ring slot `base` (absolute LDS byte address)
-    auto piece = [&](int j, unsigned base, int img, int y0, int x0, bool live) {
+    // per-tile scalars of the tile under the staging cursor: its byte offsets and its edge mask (bit k set = the halo
+    // side k lies outside the image; bit 4 always set: lanes beyond the halo tile never fetch)
+    struct TileS {
+        unsigned soP, soQ, edge;
+    };
+    auto tile_scalars = [&](int img, int y0, int x0) {
+        TileS t;
+        const unsigned pix = (unsigned)((img * a.H + y0) * a.W + x0);
+        t.soP = pix * (unsigned)cstrideP + soP;
+        t.soQ = pix * (unsigned)cstrideQ + soQ;
+        t.edge = (unsigned)((y0 == 0) | ((y0 + G::TH >= a.H) << 1) | ((x0 == 0) << 2) | ((x0 + TW >= a.W) << 3)) | 16u;
+        return t;
+    };
+    // piece j (0 .. NPW - 1) into ring slot `base` (absolute LDS byte address)
+    auto piece = [&](int j, unsigned base, const TileS& t) {
         if (j < NPW_P) {
             const int pc = j * NW + wave;
             const bool real = (j + 1) * NW <= NPC_P || pc < NPC_P;  // wave-uniform
-            const int gy = y0 - 1 + (p_yx[j] & 0xff), gx = x0 - 1 + (p_yx[j] >> 8);
-            const bool ok = live && real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-                            (NPP % 8 == 0 || pc * 8 + prow < NPP);
-            const unsigned vo = ok ? (unsigned)(((img * a.H + gy) * a.W + gx) * cstrideP) + colsrc : OOB;
-            dma_piece(r_p, real ? base + pc * 1024 : sink, vo, soP);
+            const unsigned hit = pflags & (t.edge << (5 * j));
+            const unsigned vo = hit ? OOB : pofs[j];
+            if (real) dma_piece(r_p, base + pc * 1024, vo, t.soP);
         } else {
             const int pc = (j - NPW_P) * NW + wave;
-            const int pix = pc * 8 + prow, gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-            const bool ok = live && gy < a.H && gx < a.W;
-            const unsigned vo = ok ? (unsigned)(((img * a.H + gy) * a.W + gx) * cstrideQ) + colsrc : OOB;
-            dma_piece(r_q, base + PP_BYTES + pc * 1024, vo, soQ);
+            dma_piece(r_q, base + PP_BYTES + pc * 1024, qofs[j - NPW_P], t.soQ);
         }
     };
 
@@ -641,12 +666,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // prologue: the first tile
-    {
-        const bool live = ntile < a.ntiles;
+    if (ntile < a.ntiles) {
+        const TileS t0 = tile_scalars(nimg, nty * G::TH, ntx * TW);
 #pragma unroll
-        for (int j = 0; j < G::NPW; ++j) piece(j, lds0, nimg, nty * G::TH, ntx * TW, live);
-        advance();
+        for (int j = 0; j < G::NPW; ++j) piece(j, lds0, t0);
     }
+    advance();
     int cur = 0;
 #ifdef WG_STAMP
     unsigned long long st_dma = 0, st_bar = 0, st_cmp = 0, st_n = 0;
@@ -665,9 +690,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
 #ifdef WG_STAMP
         const unsigned long long tc = __builtin_amdgcn_s_memtime();
 #endif
-        const bool more = ntile < a.ntiles;
+        const bool more = ntile < a.ntiles;  // (the wait at the top is vmcnt(0): no piece has to be issued for the count)
         const unsigned nbase = lds0 + (cur ^ 1) * BUF;
-        const int ny0 = nty * G::TH, nx0 = ntx * TW, nimgc = nimg;
+        const TileS tn = tile_scalars(nimg, nty * G::TH, ntx * TW);
         // (pb / qb carry the ring slot's offset: updated in place per tile)
         auto readP = [&](int f) {  // fragment f = (row pair, tap)
             const int rp = f / NT, tap = f % NT;
@@ -691,7 +716,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
 #pragma unroll
             for (int tap = 0; tap < NT - 2; ++tap) {
                 const int f = rp * NT + tap;
-                if (f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, nimgc, ny0, nx0, more);
+                if (more && f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, tn);
 #ifdef HIPSEG_ABLATE
                 if (!(a.debug & 4))
 #endif
@@ -708,8 +733,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
             // its first use).
             {
                 const int f = rp * NT + NT - 2;
-                if (f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, nimgc, ny0, nx0, more);
-                if ((f + 1) % 3 == 0 && (f + 1) / 3 < G::NPW) piece((f + 1) / 3, nbase, nimgc, ny0, nx0, more);
+                if (more && f % 3 == 0 && f / 3 < G::NPW) piece(f / 3, nbase, tn);
+                if (more && (f + 1) % 3 == 0 && (f + 1) / 3 < G::NPW) piece((f + 1) / 3, nbase, tn);
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb) {
 #ifdef HIPSEG_ABLATE
@@ -996,7 +1021,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     for (int ab = 0; ab < 1; ++ab) {
         int rc;
         static const bool no_tr16 = getenv("HIPSEG_NO_WGRAD_TR16") != nullptr;  // A/B switch
-        const bool tr16 = dma && !no_tr16 && !dbg && mode == HIPSEG_CONV3 && CU % 64 == 0 && CV % 64 == 0 &&
+        const bool tr16 = dma && !no_tr16 && !dbg && mode == HIPSEG_CONV3 && CU % 64 == 0 && CV % 64 == 0 && H % 16 == 0 &&
+                          W % 16 == 0 &&
                           (CU1 == 0 || CU0 % 64 == 0) &&
                           (size_t)B * H * W * (size_t)(CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1)) * 2 <= ((size_t)1 << 30);
         if (tr16)
