@@ -165,16 +165,17 @@ def _config_index(args, world):
 
 
 # HBM traffic of the roofline kernel comes from committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share
-# a pass; PMC collection cannot run inside the timed bench): profiles/r02_pmc_traffic.json, made by
-# scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --loop eager`.
+# a pass; PMC collection cannot run inside the timed bench): profiles/r03_pmc_traffic.json, made by
+# scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --loop eager`
+# (scripts/pmc.sh; the worker itself runs under the profiler: HIPSEG_BENCH_WORKER=1).
 # The file records the sha256 of the kernel sources it was measured on; a mismatch with the sources of THIS run means
 # the numbers are stale and `traffic` is reported as null.
-_PMC_FILE = "r02_pmc_traffic.json"
+_PMC_FILE = "r03_pmc_traffic.json"
 # roofline key -> (kernels whose launches are counted, helper kernels whose bytes are added to them)
-_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": (("wgrad_dma_kernel<9,",), ("wgrad_reduce3_wide",)),
-                "conv_igemm<bf16,CONV3,BN128>": (("conv3_ring64_kernel", "conv_igemm_dma_kernel<0, 128,",
+_PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": (("wgrad3_tr16_kernel", "wgrad_dma_kernel<9,"), ("wgrad_reduce3_wide",)),
+                "conv_igemm<bf16,CONV3,BN128>": (("conv3_m16_kernel", "conv3_ring64_kernel", "conv_igemm_dma_kernel<0, 128,",
                                                   "conv_igemm_dma_kernel<0, 64, 16"), ())}
-_PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "bn.hip", "common.h")
+_PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "conv3_m16.hip", "conv_args.h", "bn.hip", "common.h")
 
 
 def kernel_source_hash():

@@ -28,7 +28,7 @@ cd /tmp && export TMPDIR=/tmp
 export HIPSEG_BENCH_WORKER=1
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
-echo "rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 bench.py --no-cpu-baseline --no-roofline --loop eager --optimizer hip --steps 2 --warmup 1 $@" > $out/cmd.txt
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --loop eager --steps 2 --warmup 1 "$@" > $out/bench.json 2> $out/bench.err
+echo "rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 bench.py --no-cpu-baseline --no-roofline --no-eager --loop eager --optimizer hip --steps 2 --warmup 1 $@" > $out/cmd.txt
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-eager --loop eager --steps 2 --warmup 1 "$@" > $out/bench.json 2> $out/bench.err
 tail -2 $out/bench.err
 ls $out

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 export HIPSEG_BENCH_WORKER=1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-eager --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-160
 f=$(find $out -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv
 python3 $GRAFT_REPO_ROOT/scripts/stats_table.py $out/kernel_stats.csv 28 30
