@@ -1,0 +1,83 @@
+// Block-level entry points: the whole launch sequence of one ConvBlock forward / backward behind ONE C call.
+// Replaces ConvBlock.forward / its autograd backward (/root/reference/models/processing_blocks.py:40-52 and :69-77,
+// :108-109 for the pooled / dual-source forms) for callers that launch eagerly: the reference's unchanged
+// TrainingWrapper.train (models/model_wrappers.py:162-180) issues every step from Python, and 13 ctypes calls + their
+// argument marshalling per block cost more host time than the GPU needs for the kernels of the small layers.
+// Nothing is computed here: the functions chain the per-op entry points of this library on the given stream, with the
+// workspaces the caller allocated.
+#include "common.h"
+
+static inline const float* bnv(const float* bn, int C, int i) { return bn + (size_t)i * C; }
+
+extern "C" size_t hipseg_convblock_size(void) { return sizeof(hipseg_convblock_t); }
+
+// conv3x3 (+bias, + batch statistics) -> BatchNorm parameters of this forward -> BN-apply + ReLU (+ 2x2 max-pool)
+static int conv_bn_relu(const hipseg_convblock_t* a, const void* in0, int c0, const void* in1, int c1, const void* wp,
+                        const float* b, const float* g, const float* be, float* rm, float* rv, int64_t* nbt, void* raw,
+                        void* act, float* bn, int pool, hipseg_stream_t s) {
+    const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
+    float *mean = bn, *invstd = bn + C, *scale = bn + 2 * (size_t)C, *shift = bn + 3 * (size_t)C;
+    if (a->train) {
+        if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, in0, c0, in1, c1, wp, b, raw, C, nullptr, 0, a->stats, B, H, W, s))
+            return rc;
+        const int rows = hipseg_conv_stats_rows(dt, HIPSEG_CONV3, c0, c1, C, 0, B, H, W);
+        if (int rc = hipseg_bn_finalize(a->stats, rows, C, (double)B * H * W, g, be, a->eps, a->momentum, rm, rv, nbt, mean,
+                                        invstd, scale, shift, s))
+            return rc;
+    } else {
+        if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, in0, c0, in1, c1, wp, b, raw, C, nullptr, 0, nullptr, B, H, W, s))
+            return rc;
+        if (int rc = hipseg_bn_eval_params(g, be, rm, rv, a->eps, C, mean, invstd, scale, shift, s)) return rc;
+    }
+    return hipseg_bn_relu_apply(dt, raw, scale, shift, act, B, H, W, C, pool, s);
+}
+
+extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stream_t s) {
+    HS_REQUIRE(a && a->x0 && a->wp1 && a->wp2 && a->raw1 && a->a1 && a->raw2 && a->out && a->bn1 && a->bn2,
+               "convblock_forward: null operand");
+    HS_REQUIRE(!a->train || a->stats, "convblock_forward: train mode needs the statistics workspace");
+    if (int rc = conv_bn_relu(a, a->x0, a->C0, a->x1, a->C1, a->wp1, a->b1, a->g1, a->be1, a->rm1, a->rv1, a->nbt1, a->raw1,
+                              a->a1, a->bn1, 0, s))
+        return rc;
+    return conv_bn_relu(a, a->a1, a->Cout, nullptr, 0, a->wp2, a->b2, a->g2, a->be2, a->rm2, a->rv2, a->nbt2, a->raw2, a->out,
+                        a->bn2, a->pool, s);
+}
+
+// backward through [pool](relu(bn(raw))): [dbeta | dgamma] -> sums, conv-bias gradient -> dbias, d(raw) -> draw
+static int bn_relu_bwd(const hipseg_convblock_t* a, const void* dy, const void* raw, const float* bn, int pool, float* sums,
+                       float* dbias, void* draw, hipseg_stream_t s) {
+    const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
+    const int nblk = hipseg_bn_bwd_blocks(B, H, W, C, dt, pool);
+    if (int rc = hipseg_bn_bwd_reduce(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), a->partial, B, H,
+                                      W, C, pool, s))
+        return rc;
+    if (int rc = hipseg_colsum_finalize(a->partial, nblk, 2, C, sums, a->train ? dbias : nullptr, s)) return rc;
+    if (int rc = hipseg_bn_bwd_apply(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), sums,
+                                     (double)B * H * W, a->train ? 0 : 1, draw, nullptr, B, H, W, C, pool, s))
+        return rc;
+    if (!a->train) return hipseg_colsum(dt, draw, (long)B * H * W, C, a->colpart, dbias, s);
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_stream_t s) {
+    HS_REQUIRE(a && a->dout && a->x0 && a->raw1 && a->a1 && a->raw2 && a->bn1 && a->bn2 && a->draw2 && a->da1 && a->draw1 &&
+                   a->dw1 && a->dw2 && a->db1 && a->db2 && a->sums1 && a->sums2 && a->partial && a->slabs && a->wp2t,
+               "convblock_backward: null operand");
+    HS_REQUIRE(a->train || a->colpart, "convblock_backward: eval mode needs the column-sum workspace");
+    HS_REQUIRE(!a->need_dx || (a->wp1t && a->dx0 && ((a->C1 == 0) == (a->dx1 == nullptr))), "convblock_backward: dx operands");
+    const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
+    // second conv layer
+    if (int rc = bn_relu_bwd(a, a->dout, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
+    if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s)) return rc;
+    if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, a->draw2, C, nullptr, 0, a->wp2t, nullptr, a->da1, C, nullptr, 0, nullptr,
+                                   B, H, W, s))
+        return rc;
+    // first conv layer
+    if (int rc = bn_relu_bwd(a, a->da1, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s)) return rc;
+    if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->x0, a->C0, a->x1, a->C1, a->draw1, C, a->dw1, a->slabs, B, H, W, s))
+        return rc;
+    if (a->need_dx)
+        return hipseg_conv_igemm(dt, HIPSEG_CONV3, a->draw1, C, nullptr, 0, a->wp1t, nullptr, a->dx0, a->C0, a->dx1, a->C1,
+                                 nullptr, B, H, W, s);
+    return HIPSEG_OK;
+}

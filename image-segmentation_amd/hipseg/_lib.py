@@ -80,12 +80,26 @@ PROTOTYPES = {
     "hipseg_augment_workspace_elems": (c_size_t, [I]),
     "hipseg_augment_params": (I, [P, P, I, I] + [c_float] * 9 + [P]),
     "hipseg_augment": (I, [P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
+    "hipseg_convblock_size": (c_size_t, []),
+    "hipseg_convblock_forward": (I, [P, P]),
+    "hipseg_convblock_backward": (I, [P, P]),
 }
+
+
+class ConvBlockArgs(ctypes.Structure):
+    """hipseg_convblock_t of include/hipseg.h (block-level entry points): raw device pointers + geometry."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("dtype", "B", "H", "W", "C0", "C1", "Cout", "train", "pool", "need_dx")]
+                + [("eps", c_float), ("momentum", c_float)]
+                + [(n, c_void_p) for n in ("x0", "x1", "wp1", "wp2", "wp1t", "wp2t", "b1", "g1", "be1", "b2", "g2", "be2",
+                                            "rm1", "rv1", "rm2", "rv2", "nbt1", "nbt2", "raw1", "a1", "raw2", "out", "bn1",
+                                            "bn2", "stats", "dout", "draw2", "da1", "draw1", "dx0", "dx1", "dw1", "dw2",
+                                            "db1", "db2", "sums1", "sums2", "partial", "slabs", "colpart")])
 
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
-         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size"}
+         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size",
+         "hipseg_convblock_size"}
 
 
 def _load():
@@ -102,6 +116,9 @@ def _load():
 
 
 lib = _load()
+if ctypes.sizeof(ConvBlockArgs) != lib.hipseg_convblock_size():
+    raise ImportError(f"hipseg_convblock_t layout mismatch: ctypes {ctypes.sizeof(ConvBlockArgs)} B, library "
+                      f"{lib.hipseg_convblock_size()} B (rebuild libhipseg.so)")
 
 
 class HipsegError(RuntimeError):

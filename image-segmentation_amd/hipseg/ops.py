@@ -351,6 +351,73 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta):
 
 
 _NO_FUSED_INFERENCE = bool(os.environ.get("HIPSEG_NO_FUSED_INFERENCE"))  # A/B switch (scripts/bench_infer.py)
+_NO_BLOCK_CALLS = bool(os.environ.get("HIPSEG_NO_BLOCK_CALLS"))  # A/B switch: per-op ctypes calls instead of one per block
+
+
+def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, grad):
+    """ConvBlock forward through ONE C call (hipseg_convblock_forward: conv -> BN statistics -> BN-apply+ReLU twice);
+    Python only allocates.  Same kernels, same order as the per-op path (_conv_bn_relu)."""
+    import ctypes
+
+    B, _, H, W = x0.shape
+    cout, dev, td = w1.shape[0], x0.device, x0.dtype
+    if grad:
+        wp1, wp1t = _pack_conv_both(w1, dt)
+        wp2, wp2t = _pack_conv_both(w2, dt)
+    else:
+        wp1, wp2, wp1t, wp2t = _pack_conv(w1, dt, False), _pack_conv(w2, dt, False), None, None
+    raw1, a1, raw2 = (nhwc_empty(B, cout, H, W, td, dev) for _ in range(3))
+    out = nhwc_empty(B, cout, H // 2, W // 2, td, dev) if pool else nhwc_empty(B, cout, H, W, td, dev)
+    bnv = _f32(8 * cout, dev)
+    stats = _f32(L.conv_mtiles(B, H, W) * 2 * cout, dev) if train else None
+    A = L.ConvBlockArgs()
+    A.dtype, A.B, A.H, A.W, A.C0, A.C1, A.Cout = dt, B, H, W, x0.shape[1], (x1.shape[1] if x1 is not None else 0), cout
+    A.train, A.pool, A.eps, A.momentum = int(train), int(pool), BN_EPS, BN_MOMENTUM
+    A.x0, A.x1, A.wp1, A.wp2 = ptr(x0), ptr(x1), ptr(wp1), ptr(wp2)
+    A.b1, A.g1, A.be1, A.b2, A.g2, A.be2 = ptr(b1), ptr(g1), ptr(be1), ptr(b2), ptr(g2), ptr(be2)
+    A.rm1, A.rv1, A.rm2, A.rv2, A.nbt1, A.nbt2 = ptr(rm1), ptr(rv1), ptr(rm2), ptr(rv2), ptr(nbt1), ptr(nbt2)
+    A.raw1, A.a1, A.raw2, A.out = ptr(raw1), ptr(a1), ptr(raw2), ptr(out)
+    A.bn1, A.bn2, A.stats = bnv.data_ptr(), bnv.data_ptr() + 16 * cout, ptr(stats)
+    L.convblock_forward(ctypes.addressof(A), _stream())
+    if grad:
+        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv)
+        ctx.train, ctx.pool, ctx.dt, ctx.blk = train, pool, dt, A
+        ctx.small = (b1, g1, be1, b2, g2, be2)
+    return out
+
+
+def _block_backward(ctx, dout):
+    """the matching backward through hipseg_convblock_backward (BN backward x2, weight gradients x2, data gradients)."""
+    import ctypes
+
+    x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv = ctx.saved_tensors
+    A, dt, train, pool = ctx.blk, ctx.dt, ctx.train, ctx.pool
+    B, C, H, W = raw2.shape
+    dev, td = raw2.device, raw2.dtype
+    dout = as_nhwc(dout, td)
+    b1, g1, be1, b2, g2, be2 = ctx.small
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    need0 = ctx.needs_input_grad[0]
+    need1 = x1 is not None and ctx.needs_input_grad[1]
+    draw, da1 = nhwc_empty(B, C, H, W, td, dev), nhwc_empty(B, C, H, W, td, dev)  # (d raw1 re-uses d raw2's buffer)
+    dx0 = dx1 = None
+    if need0 or need1:
+        dx0 = nhwc_empty(B, c0, H, W, td, dev)
+        dx1 = nhwc_empty(B, c1, H, W, td, dev) if c1 else None
+    dw1, dw2, db1, db2 = grad_out(w1), grad_out(w2), grad_out(b1), grad_out(b2)
+    sums1, sums2 = grad_out_pair(be1, g1), grad_out_pair(be2, g2)
+    nblk = max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0))
+    partial = _f32(nblk * 2 * C, dev)
+    slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, c0 + c1, C, B, H, W), L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W)), dev)
+    colpart = None if train else _f32(L.colsum_blocks(B * H * W, C, dt) * C, dev)
+    A.dout, A.draw2, A.da1, A.draw1, A.dx0, A.dx1 = ptr(dout), ptr(draw), ptr(da1), ptr(draw), ptr(dx0), ptr(dx1)
+    A.dw1, A.dw2, A.db1, A.db2, A.sums1, A.sums2 = ptr(dw1), ptr(dw2), ptr(db1), ptr(db2), ptr(sums1), ptr(sums2)
+    A.partial, A.slabs, A.colpart = ptr(partial), ptr(slabs), ptr(colpart)
+    A.wp1t, A.wp2t, A.need_dx = ptr(wp1t), ptr(wp2t), int(dx0 is not None)
+    L.convblock_backward(ctypes.addressof(A), _stream())
+    return (dx0, dx1, dw1, db1, sums1[C:], sums1[:C], dw2, db2, sums2[C:], sums2[:C], None, None, None, None, None, None,
+            None, None, None)
 
 
 class ConvBlockFn(torch.autograd.Function):
@@ -366,6 +433,10 @@ class ConvBlockFn(torch.autograd.Function):
         # torch.no_grad(): the caller passes whether a graph is being recorded at all)
         grad = any(ctx.needs_input_grad) and not no_grad
         inf = not grad and not train and not _NO_FUSED_INFERENCE  # nothing saved, no backward: fused inference kernels
+        ctx.blk = None
+        if PROFILE is None and not inf and not _NO_BLOCK_CALLS:  # one C call for the whole block (host cost)
+            return _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train,
+                                  pool, grad)
         raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad, inf)
         raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf)
         if inf:
@@ -377,6 +448,8 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.blk is not None:
+            return _block_backward(ctx, dout)
         x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors
         dt, train, pool = ctx.dt, ctx.train, ctx.pool
         B, C, H, W = raw2.shape

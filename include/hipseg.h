@@ -187,6 +187,37 @@ int hipseg_colsum_blocks(long npix, int C, int dtype);
 int hipseg_colsum(int dtype, const void* x, long npix, int C, float* partial, float* out,
                   hipseg_stream_t stream);
 
+/* ---- block-level entry points (csrc/block.hip) -----------------------------------------
+ * One C call = the whole launch sequence of ConvBlock.forward / its backward
+ * (models/processing_blocks.py:40-52; :69-77 with pool = 1; :108-109 with x1 = the skip tensor), for callers that
+ * launch eagerly (the reference's TrainingWrapper.train, models/model_wrappers.py:162-180).  The struct holds raw device
+ * pointers only; every buffer is allocated by the caller:
+ *   stats   : float[hipseg_conv_mtiles(B,H,W) * 2 * Cout]            (forward, train mode)
+ *   bn1/bn2 : float[4 * Cout] each = mean | invstd | scale | shift   (written by forward, read by backward)
+ *   partial : float[hipseg_bn_bwd_blocks(B,H,W,Cout,dtype,pool=0|1) * 2 * Cout] (max of both)
+ *   slabs   : float[max hipseg_wgrad_workspace_elems(...)] of the two weight gradients
+ *   colpart : float[hipseg_colsum_blocks(B*H*W, Cout, dtype) * Cout] (eval-mode backward only)
+ *   sums1/2 : float[2 * Cout] = dbeta | dgamma of the two BatchNorm layers
+ * forward : x0 (|x1) -> raw1 -> a1 -> raw2 -> out (H/2 x W/2 when pool).  wp1/wp2: packed forward operands.
+ * backward: dout -> draw2 -> dw2, da1 -> draw1 -> dw1 [, dx0 | dx1 when need_dx].  wp1t/wp2t: packed data-gradient
+ *           operands (hipseg_pack_conv_weight(..., transpose = 1)). */
+typedef struct hipseg_convblock {
+    int32_t dtype, B, H, W, C0, C1, Cout, train, pool, need_dx;
+    float eps, momentum;
+    const void *x0, *x1, *wp1, *wp2, *wp1t, *wp2t;
+    const float *b1, *g1, *be1, *b2, *g2, *be2;
+    float *rm1, *rv1, *rm2, *rv2;
+    int64_t *nbt1, *nbt2;
+    void *raw1, *a1, *raw2, *out;
+    float *bn1, *bn2, *stats;
+    const void* dout;
+    void *draw2, *da1, *draw1, *dx0, *dx1;
+    float *dw1, *dw2, *db1, *db2, *sums1, *sums2, *partial, *slabs, *colpart;
+} hipseg_convblock_t;
+size_t hipseg_convblock_size(void);
+int hipseg_convblock_forward(const hipseg_convblock_t* args, hipseg_stream_t stream);
+int hipseg_convblock_backward(const hipseg_convblock_t* args, hipseg_stream_t stream);
+
 /* ---- 1x1 stem / head ----------------------------------------------------------------
  * stem: Conv2d(Cin, Cout, 1) on an NCHW fp32 image -> NHWC activations (models/UNet.py:39,62).
  * stem_bwd: dW (Cout,Cin), db (Cout) from dY (NHWC) and the NCHW image (no data gradient:
