@@ -489,12 +489,19 @@ def worker(args, world):
         torch.cuda.synchronize()
         run = None
 
-        def capture(graph, pool=None):
-            # ONE capture recipe (HipDDP.graph_capture: observable watchdog drain + thread_local error mode), shared
-            # with tests/ddp_gpu_worker.py
+        def capture_all(fns):
+            # ONE capture recipe (HipDDP.capture_graphs -> graph_capture: observable watchdog drain + thread_local error
+            # mode, bounded retry of an invalidated capture), shared with tests/ddp_gpu_worker.py
             if ddp:
-                return HipDDP.graph_capture(graph, stream=main_stream, pool=pool)
-            return torch.cuda.graph(graph, stream=main_stream, **({"pool": pool} if pool is not None else {}))
+                return HipDDP.capture_graphs(fns, stream=main_stream, reducer=net)
+            graphs, outs, pool = [], [], None
+            for fn in fns:
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=main_stream, **({"pool": pool} if pool is not None else {})):
+                    outs.append(fn())
+                graphs.append(g_)
+                pool = g_.pool()
+            return graphs, outs
 
         def give_up(what, err):
             # no in-process fall-back: a failed capture leaves allocator / reducer state nobody should time.  Every
@@ -510,11 +517,8 @@ def worker(args, world):
         if evg:
             err = None
             try:
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with capture(ga):
-                    static_loss = fwd_bwd()  # the hooks add one external event-record node per bucket
-                with capture(gb, pool=ga.pool()):
-                    opt_step()
+                # graph A: the hooks add one external event-record node per bucket; graph B: GradScaler + Adam
+                (ga, gb), (static_loss, _) = capture_all([fwd_bwd, opt_step])
             except Exception as e:  # noqa: BLE001
                 err = e
             if not all_agree(err is None, over_rccl=True):
@@ -531,9 +535,7 @@ def worker(args, world):
             # captured on the comm stream as a forked branch that runs under the remaining backward kernels.
             err = None
             try:
-                graph = torch.cuda.CUDAGraph()
-                with capture(graph):
-                    static_loss = step()
+                (graph,), (static_loss,) = capture_all([step])
             except Exception as e:  # noqa: BLE001
                 err = e
             if not all_agree(err is None):
@@ -543,12 +545,15 @@ def worker(args, world):
                 graph.replay()
                 return static_loss
         else:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with capture(ga):
-                static_loss = fwd_bwd()
-            net.use_bucket_grads()
-            with capture(gb, pool=ga.pool()):
+            def fwd_bwd_split():
+                loss_ = fwd_bwd()
+                return loss_
+
+            def opt_after_pack():
+                net.use_bucket_grads()
                 opt_step()
+
+            (ga, gb), (static_loss, _) = capture_all([fwd_bwd_split, opt_after_pack])
 
             def run():
                 net.broadcast_buffers_now()
@@ -621,7 +626,8 @@ def worker(args, world):
         "ms_per_step_event_median": round(ev_ms[len(ev_ms) // 2], 4),
         "distributed": {"initialized": bool(ddp), "world_size": dist.get_world_size() if ddp else 1,
                         "backend": dist.get_backend() if ddp else None, "ranks_in_sync": ranks_in_sync,
-                        "capture_fence": HipDDP.last_quiesce if ddp else None, "loop": loop_used, "attempt": int(os.environ.get("HIPSEG_BENCH_ATTEMPT", "0")),
+                        "capture_fence": HipDDP.last_quiesce if ddp else None,
+                        "capture_attempts": HipDDP.last_capture_attempts if ddp else None, "loop": loop_used, "attempt": int(os.environ.get("HIPSEG_BENCH_ATTEMPT", "0")),
                         "ddp": ({"buckets": len(net.buckets), "bucket_mb": [round(b.flat.numel() * 4 / 2 ** 20, 2)
                                                                            for b in net.buckets], **net.stats}
                                 if ddp else None)},

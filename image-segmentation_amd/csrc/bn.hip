@@ -50,36 +50,36 @@ __device__ __forceinline__ void ldc(const float* __restrict__ p, float (&v)[V]) 
 // stats: [mtiles][2][C]; block = 16 channels x 16 tile slices, double accumulation.
 // stats: [mtiles][2][C].  One launch: block = 4 channels x 64 tile slices (each lane sums <= mtiles/64 rows,
 // all loads independent), double accumulation, LDS tree over the slices, then the per-channel finish.
+// One block per channel: 256 row slices, so a 2048-row statistics workspace is 8 independent loads per thread (one
+// batch of L2 round trips) instead of 32 dependent-looking iterations on C / 4 blocks (the kernel is latency-bound:
+// 16 blocks for a 64-channel layer took 5.9 us).  Fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int rstride,
                                                            int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* running_mean, float* running_var,
                                                            long long* nbt, float* mean, float* invstd, float* scale,
                                                            float* shift) {
-    __shared__ double sS[64][4], sQ[64][4];
-    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
+    __shared__ double sS[256], sQ[256];
+    const int sl = threadIdx.x, c = blockIdx.x;
     double S = 0.0, Q = 0.0;
-    if (c < C) {
 #pragma unroll 8
-        for (int t = sl; t < mtiles; t += 64) {
-            S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
-            Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
-        }
+    for (int t = sl; t < mtiles; t += 256) {
+        S += (double)stats[((size_t)t * rstride * 2 + 0) * C + c];
+        Q += (double)stats[((size_t)t * rstride * 2 + 1) * C + c];
     }
-    sS[sl][cl] = S;
-    sQ[sl][cl] = Q;
+    sS[sl] = S;
+    sQ[sl] = Q;
     __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if (sl < o) {
-            sS[sl][cl] += sS[sl + o][cl];
-            sQ[sl][cl] += sQ[sl + o][cl];
+            sS[sl] += sS[sl + o];
+            sQ[sl] += sQ[sl + o];
         }
         __syncthreads();
     }
-    if (sl == 0 && c < C) {
-        S = sS[0][cl];
-        Q = sQ[0][cl];
+    if (sl == 0) {
+        S = sS[0];
+        Q = sQ[0];
         const double m = S / count;
         double var = Q / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -438,27 +438,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 
-// out[r][c] = sum_blk partial[blk][r][c]; block = 16 columns x 16 block-slices, fixed order, one launch.
+// out[r][c] = sum_blk partial[blk][r][c]; block = 4 columns x 64 block-slices (a 16-byte run per slice: 2048 partial
+// rows are 32 loads per thread in two batches of 16; with 16 x 16 it was 128 loads on RC / 16 = 8..64 blocks), fixed
+// order, one launch.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int RC,
                                                                float* __restrict__ out, float* __restrict__ zero_out,
                                                                int nzero) {
     if (zero_out)  // rides along: an exactly-zero gradient vector (conv bias in front of a train-mode BatchNorm)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < nzero; i += gridDim.x * 256) zero_out[i] = 0.f;
-    __shared__ float sm[16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ float sm[64][5];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (c < RC) {
-        // 16 independent loads per round (same summation order): the loop is a chain of L2 round trips otherwise
 #pragma unroll 16
-        for (int b = sl; b < nblk; b += 16) s += partial[(size_t)b * RC + c];
+        for (int b = sl; b < nblk; b += 64) s += partial[(size_t)b * RC + c];
     }
     sm[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && c < RC) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sm[i][cl];
+        for (int i = 0; i < 64; ++i) t += sm[i][cl];
         out[c] = t;
     }
 }
@@ -504,7 +505,7 @@ extern "C" int hipseg_bn_finalize(float* stats, int mtiles, int C, double count,
                            (long)2 * C, rstride);
         HS_LAUNCH_CHECK("bn_finalize_stage1");
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, stats, rows, rstride, C, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, rows, rstride, C, count, gamma, beta,
                        eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), mean,
                        invstd, scale, shift);
     HS_LAUNCH_CHECK("bn_finalize");
@@ -634,7 +635,7 @@ extern "C" int hipseg_colsum_finalize(float* partial, int nblk, int rows, int C,
                                       hipseg_stream_t stream) {
     HS_REQUIRE(partial && out && nblk > 0 && rows > 0 && C > 0, "colsum_finalize: bad arguments");
     const int RC = rows * C;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(RC, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        partial, nblk, RC, out, zero_out, C);
     HS_LAUNCH_CHECK("colsum_finalize");
     return HIPSEG_OK;

@@ -90,6 +90,7 @@ class _HostEvents:
 
 class HipDDP(nn.Module):
     last_quiesce = None  # how the most recent quiesce_before_capture() fenced ("retired" / "sleep")
+    last_capture_attempts = None  # attempts the most recent capture_graphs() needed
 
     def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0,
                  broadcast_buffers=True, overlap=True, force_collectives=False, grad_in_bucket=True):
@@ -258,6 +259,44 @@ class HipDDP(nn.Module):
         if pool is not None:
             kw["pool"] = pool
         return torch.cuda.graph(graph, **kw)
+
+    @staticmethod
+    def capture_graphs(fns, stream=None, reducer=None, attempts=3):
+        """Capture each callable of `fns` into its own hipGraph (later ones allocate from the first one's pool) with
+        graph_capture(), and RETRY a failed capture a bounded number of times.  Returns (graphs, results).
+        Why a retry: with a process group alive, a capture is occasionally invalidated before its FIRST kernel launch
+        (hipErrorStreamCaptureInvalidated reported by that launch; seen in about 1 of 5 runs of the event-graph test
+        in rounds 2 and 3, also with the watchdog's work list observably empty and thread_local capture mode -- the
+        trigger inside the HIP runtime / RCCL threads is not identified).  A capture executes nothing, so a failed one
+        leaves no device-side effect; the reducer's per-backward state is re-armed (reset()) and fresh graph objects
+        are used.  The attempt count is reported (`last_capture_attempts`)."""
+        last = None
+        for attempt in range(attempts):
+            graphs, outs, pool = [], [], None
+            try:
+                for fn in fns:
+                    g = torch.cuda.CUDAGraph()
+                    with HipDDP.graph_capture(g, stream=stream, pool=pool):
+                        outs.append(fn())
+                    graphs.append(g)
+                    pool = g.pool()
+                HipDDP.last_capture_attempts = attempt + 1
+                return graphs, outs
+            except Exception as e:  # noqa: BLE001
+                last = e
+                import sys
+
+                print(f"[HipDDP] hipGraph capture attempt {attempt + 1}/{attempts} failed: {e!r}"[:400], file=sys.stderr,
+                      flush=True)
+                graphs = outs = None
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+                if reducer is not None:
+                    reducer.reset()
+        HipDDP.last_capture_attempts = attempts
+        raise last
 
     def remove_hooks(self):
         """detach this reducer from the module's parameters (before wrapping the same module again)."""

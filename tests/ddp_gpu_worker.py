@@ -107,12 +107,17 @@ def case_overlapped_allreduce_captured_in_one_hipgraph(pg):
         m1, o1, sc1 = make()
         ddp = HipDDP(m1, force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
         losses = [float(train_step(ddp, o1, sc1)) for _ in range(3)]  # eager warm-up steps 0..2
-        graph = torch.cuda.CUDAGraph()
-        n0 = ddp.stats["comm_stream_collectives"]
-        # the ONE capture recipe bench.py uses too: observable watchdog drain + thread_local capture error mode
-        with HipDDP.graph_capture(graph, stream=s):
-            static_loss = train_step(ddp, o1, sc1)
-        assert ddp.stats["comm_stream_collectives"] - n0 == len(ddp.buckets)  # captured, not skipped
+        n0 = [0]
+
+        def captured_step():
+            n0[0] = ddp.stats["comm_stream_collectives"]
+            return train_step(ddp, o1, sc1)
+
+        # the ONE capture recipe bench.py uses too: observable watchdog drain + thread_local capture error mode + a
+        # bounded retry of an invalidated capture (HipDDP.capture_graphs)
+        (graph,), (static_loss,) = HipDDP.capture_graphs([captured_step], stream=s, reducer=ddp)
+        print("capture attempts:", HipDDP.last_capture_attempts, flush=True)
+        assert ddp.stats["comm_stream_collectives"] - n0[0] == len(ddp.buckets)  # captured, not skipped
         # capture only records; replays are steps 3, 4, 5
         for _ in range(3):
             graph.replay()
@@ -181,13 +186,16 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
         print("quiesce:", how, flush=True)
         # ("retired": the flight recorder showed the watchdog's work list empty; "sleep": not observable on this build)
         assert how in ("retired", "sleep")
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         c0 = ddp.stats["comm_stream_collectives"]
-        with HipDDP.graph_capture(ga, stream=s):
-            static_loss = fwd_bwd(m1, o1, sc1)
-        with HipDDP.graph_capture(gb, stream=s, pool=ga.pool()):
-            opt_step(o1, sc1)
-        assert ddp.stats["event_records"] == 4 * nb            # one external record node per bucket in the graph
+        ev0 = [0]
+
+        def cap_fwd_bwd():
+            ev0[0] = ddp.stats["event_records"]
+            return fwd_bwd(m1, o1, sc1)
+
+        (ga, gb), (static_loss, _) = HipDDP.capture_graphs([cap_fwd_bwd, lambda: opt_step(o1, sc1)], stream=s, reducer=ddp)
+        print("capture attempts:", HipDDP.last_capture_attempts, flush=True)
+        assert ddp.stats["event_records"] - ev0[0] == nb       # one external record node per bucket in the graph
         assert ddp.stats["comm_stream_collectives"] == c0      # and NO collective inside the capture
         assert [b for b in ddp._ready_order] and len(ddp._ready_order) == nb
         # (with ONE rank the all-reduce is an identity, so a collective that ran too early would go unnoticed in the
