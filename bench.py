@@ -639,6 +639,11 @@ def worker(args, world):
     # (every rank runs the steps -- they contain collectives -- rank 0 reports)
     if not args.no_roofline:
         ops.PROFILE = []
+        if split:
+            net.broadcast_buffers_now()
+        step()  # (untimed: creates the timing events once -- ops._EVENT_POOL)
+        torch.cuda.synchronize()
+        ops.PROFILE = []
         nprof = 3
         for _ in range(nprof):
             if split:

@@ -129,10 +129,16 @@ _TAPS = {L.CONV3: 9, L.CONV1: 1, L.CONV2S2: 4, L.CONVT: 1}
 _MODE_NAME = {L.CONV3: "CONV3", L.CONV1: "CONV1", L.CONV2S2: "CONV2S2", L.CONVT: "CONVT"}
 
 
+_EVENT_POOL = []  # timing events are created once: building two per launch costs the eager profiling loop ~10 us each
+
+
 def _timed(key, flops, fn, *args):
     if PROFILE is None:
         return fn(*args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    i = 2 * len(PROFILE)
+    while len(_EVENT_POOL) < i + 2:
+        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+    e0, e1 = _EVENT_POOL[i], _EVENT_POOL[i + 1]
     e0.record()
     fn(*args)
     e1.record()

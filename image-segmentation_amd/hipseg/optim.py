@@ -109,6 +109,8 @@ class Adam(torch.optim.Optimizer):
     def state_dict(self):
         """torch.optim.Adam-compatible: per-parameter `step` (the group's device counter), `exp_avg`, `exp_avg_sq`."""
         for gi, group in enumerate(self.param_groups):
+            if gi not in self._hip and gi not in getattr(self, "_loaded_steps", {}):
+                continue  # no device counter and nothing loaded: leave whatever `step` entries exist untouched
             n = self.step_count(gi)
             for p in group["params"]:
                 if "exp_avg" in self.state.get(p, {}):
@@ -125,6 +127,10 @@ class Adam(torch.optim.Optimizer):
                 self._loaded_steps[gi] = max(steps)
 
     def step_count(self, group=0):
-        """number of applied (non-skipped) steps of a group (host sync)."""
+        """number of applied (non-skipped) steps of a group (host sync).  The count is PER GROUP (one device counter),
+        not per parameter as in torch.optim.Adam: a parameter whose gradient is None on some steps shares the bias
+        correction of its group.  Right after load_state_dict() (device state not rebuilt yet) it is the loaded count."""
         st = self._hip.get(group)
-        return 0 if st is None else int(st["counter"][0])
+        if st is None:
+            return int(getattr(self, "_loaded_steps", {}).get(group, 0))
+        return int(st["counter"][0])

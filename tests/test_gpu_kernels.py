@@ -493,6 +493,14 @@ def test_hip_adam_state_dict_roundtrip_with_torch_adam():
     cont = [p.detach().clone().requires_grad_(True) for p in half]
     o2 = Adam(cont, **kw)
     o2.load_state_dict(sd)
+    # a checkpoint saved right after resuming (before any step) must keep the step count: with step = 0 the bias
+    # correction would restart and the first update after the next resume would be ~10x too large
+    assert o2.step_count() == 3
+    sd_again = o2.state_dict()
+    assert float(sd_again["state"][0]["step"]) == 3.0
+    o2b = Adam([p.detach().clone().requires_grad_(True) for p in half], **kw)
+    o2b.load_state_dict(sd_again)
+    assert o2b.step_count() == 3
     run(Adam, cont, grads[3:], opt=o2)
     assert o2.step_count() == 6
     for a, b in zip(cont, full):
