@@ -34,6 +34,9 @@
 int conv3_m16_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
 int conv3_m16_stats_rows(int rows, int B, int H, int W);
 int conv3_m16_launch(const ConvArgs& a, int rows, hipStream_t s);
+// LDS-free streaming kernel for the small-channel ConvTranspose2d stages (convt_stream.hip)
+int convt_stream_applies(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
+int convt_stream_launch(const ConvArgs& a, int mode, hipStream_t s);
 
 namespace {
 
@@ -1540,6 +1543,7 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
         {
             if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_launch(a, r16, s);
+            if (!dbg && convt_stream_applies(dtype, mode, C0, C1, N0, N1, B, H, W)) return convt_stream_launch(a, mode, s);
         }
         if (a.vec_ok && !no_dma && buf_ok) {
             // ConvTranspose2d forward / data gradient as a one-tap GEMM on pixel-major 64-channel stages

@@ -527,6 +527,55 @@ class ConvT2x2Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+class Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(C0 + C1, Cout, kernel_size=1) on NHWC activations, optionally on cat([x0, x1], dim=1) without building
+    the concatenation (models/prompt_segmentation.py:55,88-89: `prompt_fusion` on cat([attention_output,
+    prompt_embedding])).  Forward / data gradient = the implicit-GEMM entry point in mode CONV1 (dual source / dual
+    destination), weight gradient = hipseg_conv_wgrad in mode CONV1, bias gradient = the column sum."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w, b):
+        dt = _dt(x0)
+        B, c0, H, W = x0.shape
+        c1 = x1.shape[1] if x1 is not None else 0
+        cout = w.shape[0]
+        if w.shape[1] != c0 + c1 or tuple(w.shape[2:]) != (1, 1):
+            raise ValueError(f"Conv1x1Fn: weight {tuple(w.shape)} does not match {c0}+{c1} input channels")
+        if x1 is not None and (x1.shape[0] != B or x1.shape[2:] != x0.shape[2:] or x1.dtype != x0.dtype):
+            raise ValueError(f"Conv1x1Fn: second source {tuple(x1.shape)} does not match {tuple(x0.shape)}")
+        wp = _pack_conv(w, dt, False)
+        y = nhwc_empty(B, cout, H, W, x0.dtype, x0.device)
+        igemm(dt, L.CONV1, x0, c0, x1, c1, wp, b, y, cout, None, 0, None, B, H, W)
+        ctx.save_for_backward(x0, x1, w)
+        ctx.dt, ctx.bias = dt, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, w = ctx.saved_tensors
+        dt = ctx.dt
+        B, c0, H, W = x0.shape
+        c1 = x1.shape[1] if x1 is not None else 0
+        cout = w.shape[0]
+        dev = x0.device
+        dy = as_nhwc(dy, x0.dtype)
+        dw = grad_out(w)
+        _wgrad(dt, L.CONV1, x0, x1, dy, dw, B, H, W)
+        db = None
+        if ctx.bias is not None:
+            npix = B * H * W
+            part = _f32(L.colsum_blocks(npix, cout, dt) * cout, dev)
+            db = grad_out(ctx.bias)
+            L.colsum(dt, ptr(dy), npix, cout, ptr(part), ptr(db), _stream())
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            wpt = _pack_conv(w, dt, True)
+            dx0 = nhwc_empty(B, c0, H, W, x0.dtype, dev)
+            dx1 = nhwc_empty(B, c1, H, W, x0.dtype, dev) if c1 else None
+            igemm(dt, L.CONV1, dy, cout, None, 0, wpt, None, dx0, c0, dx1, c1, None, B, H, W)
+        return dx0, dx1, dw, db
+
+
 class BilinearFn(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) (models/processing_blocks.py:107)."""
 

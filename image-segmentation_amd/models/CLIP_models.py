@@ -56,19 +56,22 @@ class ClipUnet(UNet):
     @torch.compiler.disable
     def forward(self, X):
         clip_features = self.clip_feature_extractor(X)
+        return self._trunk(X, fuse=lambda h, skips: _fuse_clip(self, h, clip_features))
 
-        def fuse(h, skips):
-            if self.run_dead_bottleneck and self.bottleneck.training:
-                with torch.no_grad():
-                    self.bottleneck(h)  # BatchNorm bookkeeping only (see the class docstring)
-            B, _, H, W = h.shape
-            ref = h.new_empty((B, 512, H, W), device="meta")
-            y = self.cross_attention_fusion(ref, clip_features)
-            if self.run_dead_bottleneck and self.bottleneck.training and torch.is_grad_enabled() and y.requires_grad:
-                y = _DeadBranchZeroGrads.apply(y, *[p for p in self.bottleneck.parameters() if p.requires_grad])
-            return y
 
-        return self._trunk(X, fuse=fuse)
+def _fuse_clip(model, h, clip_features):
+    """CrossAttentionFusion(bottleneck(h), clip) of ClipUnet / ClipUnetPrompt: the bottleneck's output never reaches
+    the result (see ClipUnet's docstring); its train-mode bookkeeping and zero gradients are kept."""
+    dead = model.run_dead_bottleneck and model.bottleneck.training
+    if dead:
+        with torch.no_grad():
+            model.bottleneck(h)  # BatchNorm bookkeeping only
+    B, _, H, W = h.shape
+    ref = h.new_empty((B, 512, H, W), device="meta")
+    y = model.cross_attention_fusion(ref, clip_features)
+    if dead and torch.is_grad_enabled() and y.requires_grad:
+        y = _DeadBranchZeroGrads.apply(y, *[p for p in model.bottleneck.parameters() if p.requires_grad])
+    return y
 
 
 class ClipAutoencoder(nn.Module):

@@ -473,9 +473,62 @@ def gen_round3():
     print("models_r3.npz", len(out))
 
 
+def gen_round3_prompt():
+    """Round 3: the reference ClipUnetPrompt (models/prompt_segmentation.py:32-95; the model scripts/prompt_train.py:55
+    trains) with an injected CLIP feature vector (the real extractor is a network fetch), nn.BCEWithLogitsLoss on its
+    1-channel logits (the pinnable half of HybridLossBinary)."""
+    import models.prompt_segmentation as ref_prompt  # reference
+
+    out = {}
+    feats = T("prompt.feats", (2, 512), -1.0, 1.0)
+
+    class FakeExtractor(nn.Module):
+        def __init__(self, train=False):
+            super().__init__()
+
+        def forward(self, x):
+            return feats
+
+    ref_prompt.ClipFeatureExtractor = FakeExtractor
+    m = ref_prompt.ClipUnetPrompt()
+    fill.fill_state_dict(m.state_dict())
+    x = T("prompt.x", (2, 3, 64, 64))
+    heat = T("prompt.heat", (2, 1, 64, 64))
+    t = torch.from_numpy((fill.uniform("prompt.t", (2, 64, 64), 0.0, 1.0) > 0.5).astype(np.float32))
+    out["prompt/state_keys"] = np.array(list(m.state_dict().keys()))
+    m.eval()
+    with torch.no_grad():
+        out["prompt/eval_logits"] = npy(m(x, heat))
+        pe = m.prompt_encoder(heat)
+        out["prompt/eval_prompt_embedding_stat"] = np.array([float(pe.double().sum()), float(pe.double().abs().sum())])
+    m.train()
+    logits = m(x, heat)
+    loss = nn.BCEWithLogitsLoss()(logits, t.unsqueeze(1))
+    loss.backward()
+    out["prompt/train_logits"] = npy(logits)
+    out["prompt/bce_loss"] = npy(loss)
+    for k, p in m.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out[f"prompt/gradstat/{k}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()),
+                                                float(g.double().pow(2).sum())])
+    params = dict(m.named_parameters())
+    for k in ("prompt_fusion.bias", "prompt_encoder.enc1.block.0.conv.0.weight",
+              "prompt_encoder.enc2.block.0.conv.3.weight", "out.weight"):
+        out[f"prompt/grad/{k}"] = npy(params[k].grad)
+    out["prompt/grad/prompt_fusion.weight[:16]"] = npy(params["prompt_fusion.weight"].grad[:16])  # (full: 2 MiB)
+    for k, b in m.named_buffers():
+        if k.startswith(("prompt_encoder.enc1", "bottleneck")):
+            out[f"prompt/buf/{k}"] = npy(b)
+    np.savez_compressed(os.path.join(HERE, "prompt_r3.npz"), **out)
+    print("prompt_r3.npz", len(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "round3":
         gen_round3()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round3_prompt":
+        gen_round3_prompt()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "records":  # regenerate one fixture file only
         gen_records()
@@ -490,3 +543,4 @@ if __name__ == "__main__":
     gen_records()
     gen_round2()
     gen_round3()
+    gen_round3_prompt()

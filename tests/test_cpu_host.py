@@ -85,7 +85,7 @@ def test_argument_validation_fails_loudly(L):
         L.head_fwd(L.F32, 1, 1, 1, 1, 1, 8, 8, 32, 9, 0)
 
 
-def test_dropin_modules_keep_reference_state_dict_layout(L):
+def test_dropin_modules_keep_reference_state_dict_layout(L, golden):
     from models.CLIP_models import ClipUnet
     from models.UNet import LargeUNet, UNet
     from oracle import torch_ref as R
@@ -98,6 +98,14 @@ def test_dropin_modules_keep_reference_state_dict_layout(L):
             assert tuple(sd[k].shape) == tuple(ref[k].shape) and sd[k].dtype == ref[k].dtype, k
     m = ClipUnet(clip_feature_extractor=torch.nn.Identity())
     assert list(m.state_dict()) == list(R.make_state("ClipUnet"))
+    # ClipUnetPrompt (models/prompt_segmentation.py:32-95): the key order the reference's own instance reported when the
+    # fixture was generated (tests/golden/make_golden.py gen_round3_prompt)
+    from models.prompt_segmentation import ClipUnetPrompt, PromptEncoder
+
+    mp = ClipUnetPrompt(clip_feature_extractor=torch.nn.Identity())
+    assert list(mp.state_dict()) == [str(k) for k in golden("prompt_r3")["prompt/state_keys"]]
+    assert mp.prompt_fusion.weight.shape == (512, 1024, 1, 1) and mp.out.out_channels == 1
+    assert [k for k, _ in PromptEncoder().named_children()] == ["enc1", "enc2", "enc3", "conv"]
     # the attributes models/helperFunctions.py:45-78 introspects stay JSON-serialisable
     import json
 

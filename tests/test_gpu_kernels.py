@@ -187,7 +187,10 @@ def test_conv3_dgrad_wgrad(hs, prec, td, dt, case):
 
 CONVT_CASES = [(2, 16, 8, 8, 8), (1, 64, 32, 4, 12), (1, 128, 64, 16, 16), (1, 12, 6, 5, 7),
                # the one-tap GEMM kernel (C0 % 64 == 0, N % 128 == 0): ragged tiles, several images, K chunks across taps
-               (2, 256, 128, 7, 9), (1, 512, 256, 3, 5), (3, 64, 64, 18, 17)]
+               (2, 256, 128, 7, 9), (1, 512, 256, 3, 5), (3, 64, 64, 18, 17),
+               # the LDS-free streaming kernel (convt_stream.hip: W % 16 == 0, small channel counts): forward K = 64 / 128,
+               # data gradient K = 128 / 256, a pixel count that leaves a ragged tail for the 2-block unroll
+               (2, 64, 32, 32, 48), (1, 128, 64, 16, 32), (3, 64, 32, 5, 16), (1, 64, 64, 8, 16)]
 
 
 @pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
@@ -210,6 +213,42 @@ def test_convT(hs, prec, td, dt, case):
     torch.cuda.synchronize()
     check(yy.detach(), y.detach(), td, what="convT fwd")
     check(dx_.grad, x.grad, td, what="convT dgrad")
+    assert (dw_.grad.cpu() - wr.grad).abs().max() <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
+    rt = 1e-4 if td == torch.float32 else 1e-2
+    np.testing.assert_allclose(db_.grad.cpu().numpy(), b.grad.numpy(), rtol=rt, atol=rt * float(b.grad.abs().max()))
+
+
+# B, C0, C1, Cout, H, W: the 1x1 fusion conv of ClipUnetPrompt at training size (dual source 512 + 512 -> 512 at H/8),
+# single source, ragged channel counts / pixel counts
+CONV1_CASES = [(2, 512, 512, 512, 8, 8), (1, 64, 0, 128, 16, 16), (2, 24, 8, 40, 5, 7), (1, 128, 128, 64, 12, 20)]
+
+
+@pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
+@pytest.mark.parametrize("case", CONV1_CASES, ids=[str(c) for c in CONV1_CASES])
+def test_conv1x1_dual_source_fwd_bwd(hs, prec, td, dt, case):
+    """ops.Conv1x1Fn (nn.Conv2d(k=1) on cat([x0, x1])) against F.conv2d: forward, both data gradients, weight and
+    bias gradients."""
+    B, C0, C1, Cout, H, W = case
+    ops = hs.ops
+    x0 = rnd(T("c1.x0", (B, C0, H, W), -1, 1), td).requires_grad_(True)
+    x1 = rnd(T("c1.x1", (B, C1, H, W), -1, 1), td).requires_grad_(True) if C1 else None
+    w = T("c1.w", (Cout, C0 + C1, 1, 1), -0.2, 0.2)
+    wr = rnd(w, td).requires_grad_(True)
+    b = T("c1.b", (Cout,), -0.5, 0.5).requires_grad_(True)
+    dy = rnd(T("c1.dy", (B, Cout, H, W), -1, 1), td)
+    y = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, wr, b)
+    y.backward(dy)
+    d0 = to_dev_nhwc(x0.detach(), td).requires_grad_(True)
+    d1 = to_dev_nhwc(x1.detach(), td).requires_grad_(True) if C1 else None
+    dw_ = w.cuda().requires_grad_(True)
+    db_ = b.detach().cuda().requires_grad_(True)
+    yy = ops.Conv1x1Fn.apply(d0, d1, dw_, db_)
+    yy.backward(to_dev_nhwc(dy, td))
+    torch.cuda.synchronize()
+    check(yy.detach(), y.detach(), td, what="conv1x1 fwd")
+    check(d0.grad, x0.grad, td, what="conv1x1 dgrad (first source)")
+    if C1:
+        check(d1.grad, x1.grad, td, what="conv1x1 dgrad (second source)")
     assert (dw_.grad.cpu() - wr.grad).abs().max() <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
     rt = 1e-4 if td == torch.float32 else 1e-2
     np.testing.assert_allclose(db_.grad.cpu().numpy(), b.grad.numpy(), rtol=rt, atol=rt * float(b.grad.abs().max()))

@@ -3,7 +3,10 @@
     `models.losses.HybridLossBinary` with a (B,H,W) float target (the unsqueeze path of models/losses.py:30-31) +
     `DataAugmentorPrompt` in front -- as ONE train step on the HIP path.  fp32 logits and the BCE half are pinned by
     tests/golden/models_r3.npz (reference UNet(out_channels=1) + nn.BCEWithLogitsLoss); the Dice half restates
-    segmentation_models_pytorch 0.4.0 (absent): PARITY UNPINNED, checked against oracle.torch_ref only."""
+    segmentation_models_pytorch 0.4.0 (absent): PARITY UNPINNED, checked against oracle.torch_ref only.
+  * `ClipUnetPrompt` (models/prompt_segmentation.py:32-95), the model that script trains: fp32 logits / BCE / gradients
+    against tests/golden/prompt_r3.npz (the reference's own ClipUnetPrompt with an injected CLIP vector), then bf16
+    training steps with HybridLossBinary."""
 import numpy as np
 import pytest
 import torch
@@ -131,3 +134,97 @@ def test_prompt_pipeline_augmentor_model_loss_optimizer(M):
         scaler.update()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def _prompt_model(M):
+    from models import prompt_segmentation as ps
+
+    feats = T("prompt.feats", (2, 512), -1.0, 1.0).cuda()
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            return feats
+
+    m = ps.ClipUnetPrompt(clip_feature_extractor=Fake())
+    fill.fill_state_dict(m.state_dict())
+    x = T("prompt.x", (2, 3, 64, 64)).cuda()
+    heat = T("prompt.heat", (2, 1, 64, 64)).cuda()
+    t = torch.from_numpy((fill.uniform("prompt.t", (2, 64, 64), 0.0, 1.0) > 0.5).astype(np.float32)).cuda()
+    return m.cuda(), x, heat, t
+
+
+def test_clip_unet_prompt_fp32_vs_reference_golden(M, golden):
+    g = golden("prompt_r3")
+    m, x, heat, t = _prompt_model(M)
+    with M.hipseg.precision_mode("fp32"):
+        m.eval()
+        with torch.no_grad():
+            ev = m(x, heat)
+            pe = m.prompt_encoder(heat)
+        m.train()
+        logits = m(x, heat)
+        assert logits.shape == (2, 1, 64, 64) and logits.dtype == torch.float32
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, t.unsqueeze(1))
+        bce.backward()
+    torch.cuda.synchronize()
+    assert np.abs(ev.cpu().numpy() - g["prompt/eval_logits"]).max() <= 1e-4
+    np.testing.assert_allclose([float(pe.double().sum()), float(pe.double().abs().sum())],
+                               g["prompt/eval_prompt_embedding_stat"], rtol=1e-4)
+    assert np.abs(logits.detach().cpu().numpy() - g["prompt/train_logits"]).max() <= 1e-4
+    assert abs(float(bce.detach()) - float(g["prompt/bce_loss"])) <= 1e-5
+    n = 0
+    for k, p in m.named_parameters():
+        if k.startswith("bottleneck.") or "in_proj" in k or p.grad is None:
+            continue  # dead branch / q,k rows: exactly zero here, rounding noise in the reference (as for ClipUnet)
+        if k.endswith(("conv.0.bias", "conv.3.bias")):  # conv bias before train-mode BN: true gradient 0 (+ noise)
+            continue
+        s = g[f"prompt/gradstat/{k}"]
+        gd = p.grad.double()
+        np.testing.assert_allclose([float(gd.abs().sum()), float(gd.pow(2).sum())], s[1:], rtol=5e-3, atol=1e-7, err_msg=k)
+        n += 1
+    assert n >= 50
+    params = dict(m.named_parameters())
+    for k in ("prompt_fusion.bias", "prompt_encoder.enc1.block.0.conv.0.weight",
+              "prompt_encoder.enc2.block.0.conv.3.weight", "out.weight"):
+        ref = g[f"prompt/grad/{k}"]
+        assert np.abs(params[k].grad.cpu().numpy() - ref).max() <= 1e-2 * max(np.abs(ref).max(), 1e-5), k
+    ref = g["prompt/grad/prompt_fusion.weight[:16]"]
+    assert np.abs(params["prompt_fusion.weight"].grad[:16].cpu().numpy() - ref).max() <= 1e-2 * np.abs(ref).max()
+    # train-mode BatchNorm bookkeeping of the prompt branch and of the dead bottleneck
+    bufs = dict(m.named_buffers())
+    for k in g:
+        if k.startswith("prompt/buf/"):
+            np.testing.assert_allclose(bufs[k[len("prompt/buf/"):]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_clip_unet_prompt_bf16_training_steps(M):
+    """the loop body of scripts/prompt_train.py:86-103 on the HIP path: autocast forward of (image, heat map),
+    HybridLossBinary, GradScaler + Adam; the sigmoid activation variant applies `activation` (prompt_segmentation.py:95)."""
+    from hipseg.optim import Adam
+    from models import prompt_segmentation as ps
+
+    m, x, heat, t = _prompt_model(M)
+    m.train()
+    opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    crit = M.ls.HybridLossBinary()
+    losses = []
+    for _ in range(5):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda"):
+            out = m(x, heat)
+            loss = crit(out, t)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for k, p in m.named_parameters()
+               if "in_proj" not in k or True)
+    m.activation = torch.nn.Sigmoid()
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda"):
+        y = m(x, heat)
+    assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    with pytest.raises(ValueError):
+        m(x, heat[:, :, :32])
