@@ -674,22 +674,27 @@ def worker(args, world):
     # ---- the loop the reference's UNCHANGED TrainingWrapper.train runs (models/model_wrappers.py:162-180): eager,
     # one loss.item() per step.  ms/step of that and the host time Python needs to ISSUE one step (206 launches).
     if world == 1 and not ddp and not args.no_eager:
-        for _ in range(3):
-            step()
+        for _ in range(5):
+            step().item()
         torch.cuda.synchronize()
-        issue, t0 = [], time.perf_counter()
-        nst = 10
+        issue, walls, t0 = [], [], time.perf_counter()
+        nst = 20
         for _ in range(nst):
             ti = time.perf_counter()
             l_ = step()
             issue.append(time.perf_counter() - ti)
             l_.item()
+            walls.append(time.perf_counter() - ti)
         tot = (time.perf_counter() - t0) / nst
         issue.sort()
-        out["eager"] = {"ms_per_step": round(tot * 1e3, 4), "host_issue_ms_per_step": round(issue[nst // 2] * 1e3, 4),
+        walls.sort()
+        out["eager"] = {"ms_per_step": round(tot * 1e3, 4), "ms_per_step_median": round(walls[nst // 2] * 1e3, 4),
+                        "ms_per_step_max": round(walls[-1] * 1e3, 4),
+                        "host_issue_ms_per_step": round(issue[nst // 2] * 1e3, 4),
                         "steps": nst, "images_per_s": round(args.batch / tot, 1),
                         "vs_graph": round(tot * 1e3 / ms, 4),
-                        "note": "eager loop with loss.item() per step, as model_wrappers.py:167-180"}
+                        "note": "eager loop with loss.item() per step, as model_wrappers.py:167-180 (mean over the steps; "
+                                "median and slowest step beside it)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         if args.model == "UNet":

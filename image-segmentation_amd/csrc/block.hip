@@ -43,14 +43,17 @@ extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stre
                         a->bn2, a->pool, s);
 }
 
-// backward through [pool](relu(bn(raw))): [dbeta | dgamma] -> sums, conv-bias gradient -> dbias, d(raw) -> draw
+// backward through [pool](relu(bn(raw))): [dbeta | dgamma] -> sums, conv-bias gradient -> dbias, d(raw) -> draw.
+// reduced_rows > 0: a->partial already holds that many [2][C] rows of the reduction (written by the data-gradient
+// kernel that produced dy), the reduce launch is skipped.
 static int bn_relu_bwd(const hipseg_convblock_t* a, const void* dy, const void* raw, const float* bn, int pool, float* sums,
-                       float* dbias, void* draw, hipseg_stream_t s) {
+                       float* dbias, void* draw, hipseg_stream_t s, int reduced_rows = 0) {
     const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
-    const int nblk = hipseg_bn_bwd_blocks(B, H, W, C, dt, pool);
-    if (int rc = hipseg_bn_bwd_reduce(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), a->partial, B, H,
-                                      W, C, pool, s))
-        return rc;
+    const int nblk = reduced_rows ? reduced_rows : hipseg_bn_bwd_blocks(B, H, W, C, dt, pool);
+    if (!reduced_rows)
+        if (int rc = hipseg_bn_bwd_reduce(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), a->partial,
+                                          B, H, W, C, pool, s))
+            return rc;
     if (int rc = hipseg_colsum_finalize(a->partial, nblk, 2, C, sums, a->train ? dbias : nullptr, s)) return rc;
     if (int rc = hipseg_bn_bwd_apply(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), sums,
                                      (double)B * H * W, a->train ? 0 : 1, draw, nullptr, B, H, W, C, pool, s))
@@ -69,11 +72,17 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
     // second conv layer
     if (int rc = bn_relu_bwd(a, a->dout, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
     if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s)) return rc;
-    if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, a->draw2, C, nullptr, 0, a->wp2t, nullptr, a->da1, C, nullptr, 0, nullptr,
-                                   B, H, W, s))
+    // data gradient of the second conv; where a kernel with that epilogue takes the shape it also reduces the
+    // BatchNorm-backward sums of the first layer (its output IS that layer's dy), saving a pass over da1 and raw1
+    const int fused_rows = hipseg_conv3_dgrad_bnstats_rows(dt, C, C, B, H, W);
+    if (fused_rows) {
+        if (int rc = hipseg_conv3_dgrad_bnstats(dt, a->draw2, C, a->wp2t, a->da1, C, a->raw1, a->bn1, a->partial, B, H, W, s))
+            return rc;
+    } else if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, a->draw2, C, nullptr, 0, a->wp2t, nullptr, a->da1, C, nullptr, 0,
+                                          nullptr, B, H, W, s))
         return rc;
     // first conv layer
-    if (int rc = bn_relu_bwd(a, a->da1, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s)) return rc;
+    if (int rc = bn_relu_bwd(a, a->da1, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s, fused_rows)) return rc;
     if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->x0, a->C0, a->x1, a->C1, a->draw1, C, a->dw1, a->slabs, B, H, W, s))
         return rc;
     if (a->need_dx)

@@ -59,11 +59,15 @@ struct M16Geo {
     static_assert(2 * D + 2 * NT + NPW <= 63, "vmcnt is a 6-bit counter");
 };
 
-template <int THT, bool AFF>
+// EPI: 0 = conv + bias (+ batch statistics rows when p.stats), 1 = inference epilogue relu(conv * scale + shift),
+//      2 = data gradient whose output is the dy of a BatchNorm+ReLU: besides storing it, reduce the BatchNorm-backward
+//          sums [sum g | sum g * xhat] (g = dy where relu(bn(x)) > 0) of the tile into p.stats (see the epilogue)
+template <int THT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     typedef M16Geo<THT> G;
     typedef bf16 T;
+    constexpr bool AFF = EPI == 1, BWS = EPI == 2;
     constexpr int NT = G::NT, D = G::D, PF = G::PF, HW = G::HW, NPIX = G::NPIX, NPIXA = G::NPIXA, NGRP = G::NGRP;
     constexpr int A_BYTES = G::A_BYTES, NPW = G::NPW;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -248,6 +252,60 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         ssq[k] = 0.f;
     }
     const int x = x0 + li;
+    if constexpr (BWS) {
+        // The tile just computed is dy of relu(bn(xr)) (xr = p.bw_x, the convolution output that BatchNorm normalised;
+        // same NHWC shape as this output, single destination).  bn_bwd_reduce_kernel (bn.hip) would re-read both
+        // tensors to form sum g and sum g * xhat with g = dy where xr * scale + shift > 0, xhat = (xr - mean) * invstd:
+        // formed here from the bf16-rounded output (what that kernel would read back) and one 16-byte read of xr per
+        // store.  Rows go to p.stats in the layout hipseg_colsum_finalize(nblk = tiles, rows = 2) sums.
+        const float* bn = p.bw_bn + ch0;
+        float mn[8], is[8], s2[8], sh[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(bn + 4 * h);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(bn + p.N + 4 * h);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(bn + 2 * (size_t)p.N + 4 * h);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(bn + 3 * (size_t)p.N + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mn[4 * h + k] = a[k];
+                is[4 * h + k] = c[k];
+                s2[4 * h + k] = d[k];
+                sh[4 * h + k] = e[k];
+            }
+        }
+        const T* rx = reinterpret_cast<const T*>(p.bw_x) + ch0;
+        constexpr int RB = THT < 8 ? THT : 8;  // rows of xr in flight per lane
+#pragma unroll
+        for (int b0 = 0; b0 < THT; b0 += RB) {
+            bf16x8 xr[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int y = y0 + b0 + r;
+                const bool in = y < p.H && x < p.W;
+                const long pix = in ? (long)(img * p.H + y) * p.W + x : 0;
+                xr[r] = *reinterpret_cast<const bf16x8*>(rx + pix * p.N);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int b = b0 + r, y = y0 + b;
+                const bool in = y < p.H && x < p.W;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = j * 4 + e;
+                        o[k] = (T)(acc[j][b][e] + bv[k]);
+                        const float xv = (float)xr[r][k];
+                        const float g = (in && xv * s2[k] + sh[k] > 0.f) ? (float)o[k] : 0.f;
+                        ssum[k] += g;
+                        ssq[k] += g * ((xv - mn[k]) * is[k]);
+                    }
+                if (in) *reinterpret_cast<bf16x8*>(dst + ((long)(img * p.H + y) * p.W + x) * stride) = o;
+            }
+        }
+    } else {
 #pragma unroll
     for (int b = 0; b < THT; ++b) {
         const int y = y0 + b;
@@ -266,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
                 }
             }
         if (in) *reinterpret_cast<bf16x8*>(dst + ((long)(img * p.H + y) * p.W + x) * stride) = o;
+    }
     }
     if (p.stats) {
         // one statistics row per workgroup tile; the 16 pixel columns of a channel sit in the 16 lanes of a row quad
@@ -306,12 +365,15 @@ int launch_m16(const ConvArgs& a0, hipStream_t s) {
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     a.xcd = (grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
     const int threads = 256;
-    if (a.post_scale) {
-        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, true>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, true>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+    if (a.bw_x) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 2>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 2>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+    } else if (a.post_scale) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 1>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 1>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     } else {
-        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, false>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, false>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 0>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 0>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     }
     HS_LAUNCH_CHECK("conv3_m16");
     return HIPSEG_OK;

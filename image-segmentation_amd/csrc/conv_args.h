@@ -12,6 +12,11 @@ struct ConvArgs {
     void* out0;
     void* out1;
     float* stats;
+    // data gradient feeding a BatchNorm backward (hipseg_conv3_dgrad_bnstats): bw_x = the tensor that BatchNorm
+    // normalised (same NHWC shape as out0), bw_bn = its [mean | invstd | scale | shift] x N vectors; the kernel then
+    // writes [sum g | sum g * xhat] rows of the output into `stats`.  NULL = off.
+    const void* bw_x;
+    const float* bw_bn;
     int C0, C1, N0, N1;
     int B, H, W;    // GEMM-M pixel grid
     int Hi, Wi;     // input spatial dims

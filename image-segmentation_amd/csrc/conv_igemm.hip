@@ -1484,7 +1484,8 @@ extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N
 
 static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const void* in1, int C1, const void* wp,
                            const float* bias, const float* post_scale, void* out0, int N0, void* out1, int N1,
-                           float* stats, int B, int H, int W, hipseg_stream_t stream) {
+                           float* stats, int B, int H, int W, hipseg_stream_t stream, const void* bw_x = nullptr,
+                           const float* bw_bn = nullptr) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_igemm: bad dtype %d", dtype);
     HS_REQUIRE(mode >= HIPSEG_CONV3 && mode <= HIPSEG_CONVT, "conv_igemm: bad mode %d", mode);
     HS_REQUIRE(in0 && wp && out0 && C0 > 0 && N0 > 0, "conv_igemm: null operand or empty channel range");
@@ -1501,6 +1502,8 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
     a.out0 = out0;
     a.out1 = out1;
     a.stats = stats;
+    a.bw_x = bw_x;
+    a.bw_bn = bw_bn;
     a.C0 = C0;
     a.C1 = C1;
     a.N0 = N0;
@@ -1533,7 +1536,7 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == HIPSEG_BF16) {
         static const bool no_dma = getenv("HIPSEG_NO_DMA") != nullptr;  // debugging switch: generic kernel only
-        if (wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W)) {
+        if (!bw_x && wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W)) {
             if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
             return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
         }
@@ -1541,6 +1544,11 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
+        if (bw_x) {  // (hipseg_conv3_dgrad_bnstats checked that the shape has a kernel with that epilogue)
+            const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W);
+            HS_REQUIRE(r16 && !N1, "conv3_dgrad_bnstats: no kernel with the BatchNorm-backward epilogue takes this shape");
+            return conv3_m16_launch(a, r16, s);
+        }
         {
             if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_launch(a, r16, s);
             if (!dbg && convt_stream_applies(dtype, mode, C0, C1, N0, N1, B, H, W)) return convt_stream_launch(a, mode, s);
@@ -1586,6 +1594,30 @@ extern "C" int hipseg_conv_igemm(int dtype, int mode, const void* in0, int C0, c
                                  const void* wp, const float* bias, void* out0, int N0, void* out1, int N1,
                                  float* stats, int B, int H, int W, hipseg_stream_t stream) {
     return conv_igemm_impl(dtype, mode, in0, C0, in1, C1, wp, bias, nullptr, out0, N0, out1, N1, stats, B, H, W, stream);
+}
+
+// Data gradient of a 3x3 convolution whose INPUT was relu(bn(x)) (the second convolution of a ConvBlock,
+// /root/reference/models/processing_blocks.py:43-48): out = d(loss)/d(relu(bn(x))) as hipseg_conv_igemm(CONV3, in = dY,
+// wp = the data-gradient operand) computes it, and IN THE SAME KERNEL the BatchNorm-backward sums of that output,
+// [sum g | sum g * xhat] with g = out where x * scale + shift > 0, xhat = (x - mean) * invstd -- what
+// hipseg_bn_bwd_reduce would produce from a second pass over `out` and `x`.  `partial` receives
+// hipseg_conv3_dgrad_bnstats_rows() rows of [2][N] floats for hipseg_colsum_finalize(partial, rows, 2, N, sums, ...).
+// bn = [mean | invstd | scale | shift], N floats each (the vectors hipseg_bn_finalize wrote in the forward pass).
+extern "C" int hipseg_conv3_dgrad_bnstats_rows(int dtype, int C, int N, int B, int H, int W) {
+    static const bool off = getenv("HIPSEG_NO_DGRAD_BNSTATS") != nullptr;  // A/B switch
+    if (off) return 0;
+    if (wstat_grid(dtype, HIPSEG_CONV3, C, 0, N, 0, B, H, W)) return 0;  // (that kernel has no such epilogue)
+    const int r16 = conv3_m16_rows(dtype, HIPSEG_CONV3, C, 0, N, 0, B, H, W);
+    return r16 ? conv3_m16_stats_rows(r16, B, H, W) : 0;
+}
+
+extern "C" int hipseg_conv3_dgrad_bnstats(int dtype, const void* dy, int C, const void* wp, void* out, int N, const void* x,
+                                          const float* bn, float* partial, int B, int H, int W, hipseg_stream_t stream) {
+    HS_REQUIRE(x && bn && partial, "conv3_dgrad_bnstats: null operand");
+    HS_REQUIRE(hipseg_conv3_dgrad_bnstats_rows(dtype, C, N, B, H, W) > 0,
+               "conv3_dgrad_bnstats: unsupported shape (ask hipseg_conv3_dgrad_bnstats_rows first)");
+    return conv_igemm_impl(dtype, HIPSEG_CONV3, dy, C, nullptr, 0, wp, nullptr, nullptr, out, N, nullptr, 0, partial, B, H, W,
+                           stream, x, bn);
 }
 
 // Inference form of conv3x3 -> BatchNorm(running statistics) -> ReLU in ONE kernel: the per-channel affine is applied to

@@ -10,7 +10,6 @@ import os
 import weakref
 
 import torch
-from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib as L
 
@@ -164,12 +163,11 @@ def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H,
 # version counter) and only pack individually when it is not there (stand-alone block calls, tests).
 # keyed by the weight tensor OBJECT (weakly): an entry dies with its parameter.  (Keyed by address, a freed model's entry
 # was served to a new tensor that the allocator placed at the same address with the same shape and version counter.)
-_PACKED = WeakTensorKeyDictionary()  # weight tensor (by identity) -> {dt: (version, data_ptr, wp, wpt)}
 _PLANS = weakref.WeakKeyDictionary()  # module -> {dt: _PackPlan}; dies with the module (no id() reuse aliasing)
 
 
 class _PackPlan:
-    __slots__ = ("ptrs", "params", "bufs", "desc", "max_total", "n")
+    __slots__ = ("ptrs", "owners", "params", "bufs", "desc", "max_total", "n")
 
 
 def _pack_sizes(w, kind, dt):
@@ -180,32 +178,49 @@ def _pack_sizes(w, kind, dt):
     return L.kpad(cin, dt) * L.npad(4 * cout), 4 * L.kpad(cout, dt) * L.npad(cin)
 
 
+def _scan_pack_owners(module):
+    owners = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2):
+            owners.append((m, 1))
+        elif isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3):
+            owners.append((m, 0))
+    return owners
+
+
 def prepack(module, prec):
     """Pack every 3x3 Conv2d / 2x2 ConvTranspose2d weight of `module` into its MFMA operand layouts (forward and
-    data-gradient) with ONE kernel launch.  The descriptor table and the operand buffers persist per (module, dt)."""
+    data-gradient) with ONE kernel launch.  The descriptor table and the operand buffers persist per (module, dt).
+    This runs at the head of every forward, in front of the first kernel of an eagerly launched step (the reference's
+    loop synchronises on loss.item() every step, models/model_wrappers.py:180, so the GPU idles until it returns): the
+    layer list is scanned once per module and revalidated by identity (20 `is` tests, not a walk over 86 submodules);
+    a layer added to the module later is simply packed on its own by its first convolution call."""
     import ctypes
     if os.environ.get("HIPSEG_NO_PREPACK"):  # A/B switch: per-layer pack launches
         return
     dt = L.BF16 if prec == "bf16" else L.F32
-    params = []
-    for m in module.modules():
-        if isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2):
-            params.append((m.weight, 1))
-        elif isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3):
-            params.append((m.weight, 0))
-    if not params:
-        return
-    ptrs = tuple(w.data_ptr() for w, _ in params)
-    plans = _PLANS.setdefault(module, {})
+    plans = _PLANS.get(module)
+    if plans is None:
+        plans = _PLANS[module] = {}
     plan = plans.get(dt)
-    if plan is None or plan.ptrs != ptrs:
-        dev = params[0][0].device
+    if plan is not None:
+        for (m, _), w, p0 in zip(plan.owners, plan.params, plan.ptrs):
+            if m.weight is not w or w.data_ptr() != p0:
+                plan = None  # a parameter was replaced or moved: rebuild
+                break
+    if plan is None:
+        owners = _scan_pack_owners(module)
+        if not owners:
+            return
+        params = [m.weight for m, _ in owners]
+        dev = params[0].device
         td = _tdtype(prec)
         plan = _PackPlan()
-        plan.ptrs, plan.params, plan.n = ptrs, params, len(params)
+        plan.owners, plan.params, plan.n = owners, params, len(params)
+        plan.ptrs = tuple(w.data_ptr() for w in params)
         plan.bufs, plan.max_total = [], 0
         host = ctypes.create_string_buffer(plan.n * L.pack_desc_size())
-        for i, (w, kind) in enumerate(params):
+        for i, ((_, kind), w) in enumerate(zip(owners, params)):
             n0, n1 = _pack_sizes(w, kind, dt)
             wp, wpt = torch.empty(n0, dtype=td, device=dev), torch.empty(n1, dtype=td, device=dev)
             plan.bufs.append((wp, wpt))
@@ -218,12 +233,25 @@ def prepack(module, prec):
         plan.desc = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
         plans[dt] = plan
     L.pack_batch(ptr(plan.desc), plan.n, dt, plan.max_total, _stream())
-    for (w, _), (wp, wpt) in zip(plan.params, plan.bufs):
-        _PACKED.setdefault(w, {})[dt] = (w._version, w.data_ptr(), wp, wpt)
+    for w, p0, (wp, wpt) in zip(plan.params, plan.ptrs, plan.bufs):
+        _set_cached_pack(w, dt, (w._version, p0, wp, wpt))
+
+
+# packed operands of a weight tensor: an attribute of the tensor object itself, {dt: (version, data_ptr, wp, wpt)} (dies
+# with the tensor; an attribute read instead of a weak-dictionary lookup on every convolution call)
+def _set_cached_pack(w, dt, entry):
+    c = getattr(w, "_hipseg_pack", None)
+    if c is None:
+        c = {}
+        w._hipseg_pack = c
+    c[dt] = entry
 
 
 def _cached_pack(w, dt):
-    e = _PACKED.get(w, {}).get(dt)
+    c = getattr(w, "_hipseg_pack", None)
+    if c is None:
+        return None
+    e = c.get(dt)
     if e is not None and e[0] == w._version and e[1] == w.data_ptr() and e[2].device == w.device:
         return e[2], e[3]
     return None
@@ -413,7 +441,10 @@ def _block_backward(ctx, dout):
         dx1 = nhwc_empty(B, c1, H, W, td, dev) if c1 else None
     dw1, dw2, db1, db2 = grad_out(w1), grad_out(w2), grad_out(b1), grad_out(b2)
     sums1, sums2 = grad_out_pair(be1, g1), grad_out_pair(be2, g2)
-    nblk = max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0))
+    # rows of BatchNorm-backward partial sums: the reduce kernels' blocks, or the tiles of the data-gradient kernel that
+    # reduces the first layer's sums in its epilogue (hipseg_conv3_dgrad_bnstats)
+    nblk = max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0),
+               L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W))
     partial = _f32(nblk * 2 * C, dev)
     slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, c0 + c1, C, B, H, W), L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W)), dev)
     colpart = None if train else _f32(L.colsum_blocks(B * H * W, C, dt) * C, dev)

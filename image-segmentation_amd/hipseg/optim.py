@@ -105,6 +105,18 @@ class Adam(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(active)
         return loss
 
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad.  The set_to_none form (the default, and what the reference's loops get from
+        `optimizer.zero_grad()`, models/model_wrappers.py:166,969) is the first thing an eagerly launched step does
+        after the previous step's loss.item() synchronisation: the GPU idles until the first forward kernel is queued,
+        so the generic implementation's per-parameter bookkeeping (0.13 ms for the U-Net's 76 parameters) is replaced
+        by the plain loop it amounts to."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
     # ------------------------------------------------------------------ checkpointing (torch.optim.Adam's layout)
     def state_dict(self):
         """torch.optim.Adam-compatible: per-parameter `step` (the group's device counter), `exp_avg`, `exp_avg_sq`."""

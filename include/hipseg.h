@@ -124,6 +124,21 @@ int hipseg_conv_affine_relu(int dtype, const void* in0, int C0, const void* in1,
                             const float* scale, const float* shift, void* out, int N, int B, int H, int W,
                             hipseg_stream_t stream);
 
+/* ---- data gradient + BatchNorm-backward sums in one kernel ----------------------------------------
+ * hipseg_conv3_dgrad_bnstats: out = the data gradient hipseg_conv_igemm(HIPSEG_CONV3, in0 = dy, wp = data-gradient
+ * operand) computes, for a convolution whose INPUT was relu(bn(x)); in the same kernel the BatchNorm-backward sums
+ * of `out`, [sum g | sum g * xhat] with g = out where x * scale + shift > 0 and xhat = (x - mean) * invstd, are reduced
+ * per workgroup tile into `partial` (rows x [2][N] floats) -- the rows hipseg_colsum_finalize(partial, rows, 2, N, ...)
+ * sums, and what hipseg_bn_bwd_reduce(dy = out, x, ...) would compute from a second pass over both tensors.
+ * bn = [mean | invstd | scale | shift], N floats each.  hipseg_conv3_dgrad_bnstats_rows: rows written for the shape,
+ * 0 = no kernel with that epilogue takes it (use hipseg_conv_igemm + hipseg_bn_bwd_reduce).
+ * replaces: aten::convolution_backward (input gradient) of the second Conv2d of a ConvBlock followed by the
+ *           reduction half of aten::native_batch_norm_backward + threshold_backward of the first
+ *           BatchNorm2d/ReLU (models/processing_blocks.py:43-45 under autograd). */
+int hipseg_conv3_dgrad_bnstats_rows(int dtype, int C, int N, int B, int H, int W);
+int hipseg_conv3_dgrad_bnstats(int dtype, const void* dy, int C, const void* wp, void* out, int N, const void* x,
+                               const float* bn, float* partial, int B, int H, int W, hipseg_stream_t stream);
+
 /* ---- weight gradient (MFMA, split over pixel chunks) --------------------------------
  * G[tap][u][v] = sum_pixels P[n, tap(y,x), u] * Q[n, y, x, v]
  *   mode HIPSEG_CONV3 : P = layer input (p0|p1 dual source, CU = Cin), Q = dY (CV = Cout),

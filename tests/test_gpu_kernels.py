@@ -218,6 +218,55 @@ def test_convT(hs, prec, td, dt, case):
     np.testing.assert_allclose(db_.grad.cpu().numpy(), b.grad.numpy(), rtol=rt, atol=rt * float(b.grad.abs().max()))
 
 
+# B, C (= K = N), H, W: the second conv of a ConvBlock at the U-Net's >= 128-channel levels (16- and 8-row tiles, ragged
+# borders, several channel tiles)
+DGRAD_BNSTATS_CASES = [(2, 128, 32, 32), (1, 256, 20, 36), (4, 128, 64, 64), (1, 512, 16, 16), (2, 128, 9, 17)]
+
+
+@pytest.mark.parametrize("case", DGRAD_BNSTATS_CASES, ids=[str(c) for c in DGRAD_BNSTATS_CASES])
+def test_conv3_dgrad_with_bn_backward_sums(hs, case):
+    """hipseg_conv3_dgrad_bnstats == hipseg_conv_igemm (bit for bit on the data gradient) + hipseg_bn_bwd_reduce on its
+    output (the finalised [sum g | sum g * xhat] vectors; fp32 sums in a different order)."""
+    B, C, H, W = case
+    L, ops = hs.L, hs.ops
+    td, dt = torch.bfloat16, L.BF16
+    rows = L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W)
+    assert rows > 0
+    dy = to_dev_nhwc(rnd(T("db.dy", (B, C, H, W), -1, 1), td), td)
+    raw = to_dev_nhwc(rnd(T("db.raw", (B, C, H, W), -2, 2), td), td)
+    w = T("db.w", (C, C, 3, 3), -0.05, 0.05).cuda()
+    wpt = ops._pack_conv(w, dt, True)
+    bn = torch.cat([T("db.mean", (C,), -0.5, 0.5), T("db.is", (C,), 0.5, 2.0), T("db.sc", (C,), -1.5, 1.5),
+                    T("db.sh", (C,), -0.5, 0.5)]).cuda()
+    s = ops._stream()
+    # separate kernels
+    ref = ops.nhwc_empty(B, C, H, W, td, "cuda")
+    L.conv_igemm(dt, L.CONV3, ops.ptr(dy), C, 0, 0, ops.ptr(wpt), 0, ops.ptr(ref), C, 0, 0, 0, B, H, W, s)
+    nblk = L.bn_bwd_blocks(B, H, W, C, dt, 0)
+    part = torch.empty(nblk * 2 * C, device="cuda")
+    bp = bn.data_ptr()
+    L.bn_bwd_reduce(dt, ops.ptr(ref), ops.ptr(raw), bp, bp + 4 * C, bp + 8 * C, bp + 12 * C, ops.ptr(part), B, H, W, C, 0, s)
+    want = torch.empty(2 * C, device="cuda")
+    L.colsum_finalize(ops.ptr(part), nblk, 2, C, ops.ptr(want), 0, s)
+    # fused
+    out = ops.nhwc_empty(B, C, H, W, td, "cuda")
+    part2 = torch.full((rows * 2 * C,), float("nan"), device="cuda")
+    L.conv3_dgrad_bnstats(dt, ops.ptr(dy), C, ops.ptr(wpt), ops.ptr(out), C, ops.ptr(raw), bp, ops.ptr(part2), B, H, W, s)
+    got = torch.empty(2 * C, device="cuda")
+    L.colsum_finalize(ops.ptr(part2), rows, 2, C, ops.ptr(got), 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert bool(torch.isfinite(part2).all())
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0) + 1e-6 * (B * H * W) ** 0.5, (got - want).abs().max()
+    # an exact statement on the masks: the double-precision sums from the stored tensors
+    o64, x64 = out.double(), raw.double()
+    mean, istd, sc, sh = (bn[i * C:(i + 1) * C].double().view(1, C, 1, 1) for i in range(4))
+    g = torch.where((raw.float() * sc.float() + sh.float()) > 0, o64, torch.zeros_like(o64))
+    ex = torch.cat([g.sum((0, 2, 3)), (g * ((x64 - mean) * istd)).sum((0, 2, 3))])
+    assert float((got.double() - ex).abs().max()) <= 5e-5 * max(float(ex.abs().max()), 1.0)
+
+
 # B, C0, C1, Cout, H, W: the 1x1 fusion conv of ClipUnetPrompt at training size (dual source 512 + 512 -> 512 at H/8),
 # single source, ragged channel counts / pixel counts
 CONV1_CASES = [(2, 512, 512, 512, 8, 8), (1, 64, 0, 128, 16, 16), (2, 24, 8, 40, 5, 7), (1, 128, 128, 64, 12, 20)]
@@ -409,7 +458,6 @@ def test_pack_batch_matches_per_layer_pack(hs, prec, td, dt):
                               # unpadded 3x3 shapes: the LDS-staged tile path of the batch kernel (32- and 64-wide k tiles)
                               torch.nn.Conv2d(32, 64, 3, padding=1), torch.nn.Conv2d(128, 256, 3, padding=1),
                               torch.nn.Conv2d(256, 128, 3, padding=1)).cuda()
-    ops._PACKED.clear()
     want = []
     for m in net:
         if isinstance(m, torch.nn.ConvTranspose2d):
