@@ -69,9 +69,14 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
     HS_REQUIRE(a->train || a->colpart, "convblock_backward: eval mode needs the column-sum workspace");
     HS_REQUIRE(!a->need_dx || (a->wp1t && a->dx0 && ((a->C1 == 0) == (a->dx1 == nullptr))), "convblock_backward: dx operands");
     const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
+    // both weight gradients in one launch where the pair is taken (half the partial-sum traffic): needs d(raw2) alive
+    // until d(raw1) exists, i.e. two distinct buffers
+    const bool pair = a->draw1 != a->draw2 && hipseg_conv_wgrad_pair_applies(dt, a->C0, a->C1, C, C, B, H, W);
     // second conv layer
     if (int rc = bn_relu_bwd(a, a->dout, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
-    if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s)) return rc;
+    if (!pair)
+        if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s))
+            return rc;
     // data gradient of the second conv; where a kernel with that epilogue takes the shape it also reduces the
     // BatchNorm-backward sums of the first layer (its output IS that layer's dy), saving a pass over da1 and raw1
     const int fused_rows = hipseg_conv3_dgrad_bnstats_rows(dt, C, C, B, H, W);
@@ -83,7 +88,12 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
         return rc;
     // first conv layer
     if (int rc = bn_relu_bwd(a, a->da1, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s, fused_rows)) return rc;
-    if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->x0, a->C0, a->x1, a->C1, a->draw1, C, a->dw1, a->slabs, B, H, W, s))
+    if (pair) {
+        if (int rc = hipseg_conv_wgrad_pair(dt, a->x0, a->C0, a->x1, a->C1, a->draw1, a->dw1, a->a1, C, a->draw2, a->dw2, C,
+                                            a->slabs, B, H, W, s))
+            return rc;
+    } else if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->x0, a->C0, a->x1, a->C1, a->draw1, C, a->dw1, a->slabs, B, H, W,
+                                          s))
         return rc;
     if (a->need_dx)
         return hipseg_conv_igemm(dt, HIPSEG_CONV3, a->draw1, C, nullptr, 0, a->wp1t, nullptr, a->dx0, a->C0, a->dx1, a->C1,

@@ -548,7 +548,14 @@ struct Tr16Geo {
     static_assert(LDS <= 160 * 1024 && NPC_Q % NW == 0, "geometry");
 };
 
-__global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
+// PAIR: ONE launch computes the weight gradients of TWO layers over the same pixel grid (the two convolutions of a
+// ConvBlock): problem a has tA = UT * VT channel tiles, problem b tB; each of the S pixel splits owns tA + tB
+// workgroups, so S = CUs / (tA + tB) instead of CUs / tA and CUs / tB in two launches -- the slab volume
+// (workgroups x 147 KB of fp32 partial sums, written here and read back by the reduction) of BOTH layers together is
+// what ONE layer's was.  The grid is padded to a multiple of 8 and dealt to the XCDs in contiguous runs of logical
+// ids (s-major), so the workgroups of one pixel split share an L2.
+template <bool PAIR>
+__global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2, int tA, int tB) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef Tr16Geo G;
     constexpr int NT = 9, PHW = G::PHW, NPP = G::NPP, NW = G::NW, NPC_P = G::NPC_P, NPW_P = G::NPW_P, NPW_Q = G::NPW_Q;
@@ -561,10 +568,25 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wu = wave & 3;  // pixel-row half, 16-channel u block of the wave (all 64 v channels)
-    const int bid = xcd_block(blockIdx.x, a.xcd);
-    const int vt = bid % a.VT;
-    const int ut = (bid / a.VT) % a.UT;
-    const int s = bid / (a.VT * a.UT);
+    int vt, ut, s;
+    if (PAIR) {
+        const int cpx = gridDim.x >> 3;
+        const int logical = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+        if (logical >= a.S * (tA + tB)) return;  // grid padding (whole workgroup, before any barrier)
+        s = logical / (tA + tB);
+        int rem = logical - s * (tA + tB);
+        if (rem >= tA) {  // second problem (workgroup-uniform: the arguments stay scalar)
+            rem -= tA;
+            a = b2;
+        }
+        vt = rem % a.VT;
+        ut = rem / a.VT;
+    } else {
+        const int bid = xcd_block(blockIdx.x, a.xcd);
+        vt = bid % a.VT;
+        ut = (bid / a.VT) % a.UT;
+        s = bid / (a.VT * a.UT);
+    }
     const int u0 = ut * 64, v0 = vt * 64;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;  // 1-KiB aligned (declaration): bits 5-6 are slot bits
     const unsigned sink = lds0 + 2 * BUF;
@@ -810,13 +832,25 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a) {
 #endif
 #else
     (void)a;
+    (void)b2;
+    (void)tA;
+    (void)tB;
 #endif
 }
 
 int launch_tr16(const WgArgs& a, hipStream_t s) {
-    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel), (size_t)Tr16Geo::LDS)) return rc;
-    hipLaunchKernelGGL(wgrad3_tr16_kernel, dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), Tr16Geo::LDS, s, a);
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false>), (size_t)Tr16Geo::LDS)) return rc;
+    hipLaunchKernelGGL(wgrad3_tr16_kernel<false>, dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
     HS_LAUNCH_CHECK("conv_wgrad_tr16");
+    return HIPSEG_OK;
+}
+
+int launch_tr16_pair(const WgArgs& a, const WgArgs& b, hipStream_t s) {
+    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<true>), (size_t)Tr16Geo::LDS)) return rc;
+    const int tA = a.UT * a.VT, tB = b.UT * b.VT;
+    const int grid = (a.S * (tA + tB) + 7) / 8 * 8;
+    hipLaunchKernelGGL(wgrad3_tr16_kernel<true>, dim3((unsigned)grid), dim3(512), Tr16Geo::LDS, s, a, b, tA, tB);
+    HS_LAUNCH_CHECK("conv_wgrad_tr16(pair)");
     return HIPSEG_OK;
 }
 
@@ -875,12 +909,23 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
 template <int NS, int UTL, int TG>
 __global__ __launch_bounds__(32 * UTL * NS) void wgrad_reduce3_wide_kernel(const float* __restrict__ slabs,
                                                                            float* __restrict__ dw, int S, int CU, int CV,
-                                                                           int CUp, int CVp) {
+                                                                           int CUp, int CVp,
+                                                                           const float* __restrict__ slabs2 = nullptr,
+                                                                           float* __restrict__ dw2 = nullptr, int CU2 = 0,
+                                                                           int CUp2 = 0, int yb0 = 0) {
     // a wave reads full 128-byte slab rows (32 v) per load instruction
     constexpr int UV = 32 * UTL;
     __shared__ float red[NS][UV][TG];
     const int tid = threadIdx.x, sl = tid / UV, uv = tid % UV, u = uv >> 5, v = uv & 31;
-    const int u0 = blockIdx.y * UTL, v0 = blockIdx.x * 32, t0 = blockIdx.z * TG;
+    int by = blockIdx.y;
+    if (slabs2 && by >= yb0) {  // second weight tensor of a paired launch (same S, CV): grid rows [yb0, ...)
+        by -= yb0;
+        slabs = slabs2;
+        dw = dw2;
+        CU = CU2;
+        CUp = CUp2;
+    }
+    const int u0 = by * UTL, v0 = blockIdx.x * 32, t0 = blockIdx.z * TG;
     const size_t tstride = (size_t)CUp * CVp, sstride = 9 * tstride;
     const float* src = slabs + (size_t)(u0 + u) * CVp + v0 + v + t0 * tstride;  // padded to 32: always in bounds
     float acc[TG];
@@ -1066,5 +1111,107 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
                            pl.CVp, mode, ab);
         HS_LAUNCH_CHECK("wgrad_reduce");
     }
+    return HIPSEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Paired 3x3 weight gradients (the two convolutions of a ConvBlock, same pixel grid, same Cout = CV) in ONE launch
+// of wgrad3_tr16_kernel<true> + ONE reduction launch; see the kernel's PAIR comment.
+namespace {
+
+bool tr16_shape_ok(int CU0, int CU1, int CV, int B, int H, int W) {
+    const int CU = CU0 + CU1;
+    const int cmax = CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1);
+    return CU % 64 == 0 && CV % 64 == 0 && H % 16 == 0 && W % 16 == 0 && (CU1 == 0 || CU0 % 64 == 0) &&
+           (size_t)B * H * W * (size_t)cmax * 2 <= ((size_t)1 << 30);
+}
+
+// pixel splits of the paired launch, 0 = the pair is not taken
+int pair_splits(int dtype, int CUa0, int CUa1, int CUb, int CV, int B, int H, int W) {
+    static const bool off = getenv("HIPSEG_NO_WGRAD_PAIR") != nullptr || getenv("HIPSEG_NO_WGRAD_TR16") != nullptr ||
+                            getenv("HIPSEG_NO_DMA") != nullptr;
+    if (off || dtype != HIPSEG_BF16) return 0;
+    if (!tr16_shape_ok(CUa0, CUa1, CV, B, H, W) || !tr16_shape_ok(CUb, 0, CV, B, H, W)) return 0;
+    const int tA = ((CUa0 + CUa1) / 64) * (CV / 64), tB = (CUb / 64) * (CV / 64);
+    const int ncu = device_cus();
+    const int ntiles = B * (H / 16) * (W / 16);
+    int S = ncu / (tA + tB);
+    // worth it when the paired grid still fills the chip (>= 90 % of the CUs; alone each layer fills it) and every
+    // layer would have been split at least twice on its own (otherwise there is little slab traffic to save); a pixel
+    // grid with fewer tiles than that caps the split count of either form, the pair then only adds workgroups
+    if (S < 1 || ncu / tA < 2 || ncu / tB < 2) return 0;
+    if (S >= ntiles) return ntiles;
+    if ((long)S * (tA + tB) * 10 < (long)ncu * 9) return 0;
+    return S;
+}
+
+WgArgs tr16_args(const void* p0, int CU0, const void* p1, int CU1, const void* q, int CV, float* slabs, int S, int B, int H,
+                 int W) {
+    WgArgs a;
+    a.p0 = p0;
+    a.p1 = p1;
+    a.q = q;
+    a.slabs = slabs;
+    a.CU0 = CU0;
+    a.CU1 = CU1;
+    a.CU = CU0 + CU1;
+    a.CV = CV;
+    a.UT = a.CU / 64;
+    a.VT = CV / 64;
+    a.CUp = a.CU;
+    a.CVp = CV;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.ps = 1;
+    a.PH = H;
+    a.PW = W;
+    a.pa = 0;
+    a.pb = 0;
+    a.tiles_x = W / 16;
+    a.tiles_y = H / 16;
+    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.S = S;
+    a.vec_ok_p = 1;
+    a.vec_ok_q = 1;
+    a.convt_cout = 0;
+    a.debug = 0;
+    a.xcd = 0;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int hipseg_conv_wgrad_pair_applies(int dtype, int CUa0, int CUa1, int CUb, int CV, int B, int H, int W) {
+    return pair_splits(dtype, CUa0, CUa1, CUb, CV, B, H, W) > 0 ? 1 : 0;
+}
+
+extern "C" int hipseg_conv_wgrad_pair(int dtype, const void* pa0, int CUa0, const void* pa1, int CUa1, const void* qa,
+                                      float* dwa, const void* pb, int CUb, const void* qb, float* dwb, int CV, float* slabs,
+                                      int B, int H, int W, hipseg_stream_t stream) {
+    HS_REQUIRE(pa0 && qa && dwa && pb && qb && dwb && slabs, "conv_wgrad_pair: null operand");
+    HS_REQUIRE((CUa1 == 0) == (pa1 == nullptr), "conv_wgrad_pair: pa1/CUa1 mismatch");
+    const int S = pair_splits(dtype, CUa0, CUa1, CUb, CV, B, H, W);
+    HS_REQUIRE(S > 0, "conv_wgrad_pair: the pair is not taken for this shape (ask hipseg_conv_wgrad_pair_applies first)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int CUa = CUa0 + CUa1;
+    float* slabs_b = slabs + (size_t)S * 9 * CUa * CV;  // (within hipseg_wgrad_workspace_elems of either layer)
+    const WgArgs a = tr16_args(pa0, CUa0, pa1, CUa1, qa, CV, slabs, S, B, H, W);
+    const WgArgs b = tr16_args(pb, CUb, nullptr, 0, qb, CV, slabs_b, S, B, H, W);
+    if (int rc = launch_tr16_pair(a, b, s)) return rc;
+    // one reduction launch over both weight tensors (grid rows of the second one behind the first one's)
+    if (S >= 32 && cdiv(CV, 32) * (cdiv(CUa, 4) + cdiv(CUb, 4)) < 128)
+        hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<32, 1, 3>), dim3(cdiv(CV, 32), CUa + CUb, 3), dim3(1024), 0, s, slabs, dwa,
+                           S, CUa, CV, CUa, CV, slabs_b, dwb, CUb, CUb, CUa);
+    else if (S >= 8)
+        hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<8, 4, 9>), dim3(cdiv(CV, 32), CUa / 4 + CUb / 4), dim3(1024), 0, s, slabs,
+                           dwa, S, CUa, CV, CUa, CV, slabs_b, dwb, CUb, CUb, CUa / 4);
+    else if (S >= 4)
+        hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<4, 4, 9>), dim3(cdiv(CV, 32), CUa / 4 + CUb / 4), dim3(512), 0, s, slabs,
+                           dwa, S, CUa, CV, CUa, CV, slabs_b, dwb, CUb, CUb, CUa / 4);
+    else
+        hipLaunchKernelGGL((wgrad_reduce3_wide_kernel<2, 4, 9>), dim3(cdiv(CV, 32), CUa / 4 + CUb / 4), dim3(256), 0, s, slabs,
+                           dwa, S, CUa, CV, CUa, CV, slabs_b, dwb, CUb, CUb, CUa / 4);
+    HS_LAUNCH_CHECK("wgrad_reduce(pair)");
     return HIPSEG_OK;
 }

@@ -434,7 +434,9 @@ def _block_backward(ctx, dout):
     c1 = x1.shape[1] if x1 is not None else 0
     need0 = ctx.needs_input_grad[0]
     need1 = x1 is not None and ctx.needs_input_grad[1]
-    draw, da1 = nhwc_empty(B, C, H, W, td, dev), nhwc_empty(B, C, H, W, td, dev)  # (d raw1 re-uses d raw2's buffer)
+    draw, da1 = nhwc_empty(B, C, H, W, td, dev), nhwc_empty(B, C, H, W, td, dev)
+    # d raw1 re-uses d raw2's buffer, unless both weight gradients run as ONE paired launch after d raw1 exists
+    draw1 = nhwc_empty(B, C, H, W, td, dev) if L.conv_wgrad_pair_applies(dt, c0, c1, C, C, B, H, W) else draw
     dx0 = dx1 = None
     if need0 or need1:
         dx0 = nhwc_empty(B, c0, H, W, td, dev)
@@ -448,7 +450,7 @@ def _block_backward(ctx, dout):
     partial = _f32(nblk * 2 * C, dev)
     slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, c0 + c1, C, B, H, W), L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W)), dev)
     colpart = None if train else _f32(L.colsum_blocks(B * H * W, C, dt) * C, dev)
-    A.dout, A.draw2, A.da1, A.draw1, A.dx0, A.dx1 = ptr(dout), ptr(draw), ptr(da1), ptr(draw), ptr(dx0), ptr(dx1)
+    A.dout, A.draw2, A.da1, A.draw1, A.dx0, A.dx1 = ptr(dout), ptr(draw), ptr(da1), ptr(draw1), ptr(dx0), ptr(dx1)
     A.dw1, A.dw2, A.db1, A.db2, A.sums1, A.sums2 = ptr(dw1), ptr(dw2), ptr(db1), ptr(db2), ptr(sums1), ptr(sums2)
     A.partial, A.slabs, A.colpart = ptr(partial), ptr(slabs), ptr(colpart)
     A.wp1t, A.wp2t, A.need_dx = ptr(wp1t), ptr(wp2t), int(dx0 is not None)

@@ -155,6 +155,22 @@ int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* 
                       const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
                       hipseg_stream_t stream);
 
+/* The 3x3 weight gradients of the TWO convolutions of a ConvBlock (same pixel grid, same Cout = CV) in one launch +
+ * one reduction launch: problem a = (pa0|pa1 dual source with CUa0 + CUa1 channels, qa = dY of the first conv) -> dwa
+ * (CV, CUa0 + CUa1, 3, 3); problem b = (pb with CUb channels, qb = dY of the second conv) -> dwb (CV, CUb, 3, 3).
+ * Every pixel split of the launch then owns the channel tiles of BOTH layers, so there are half as many splits as in
+ * two hipseg_conv_wgrad launches and half the fp32 partial-sum traffic (written by the MFMA kernel, read back by the
+ * reduction).  Same arithmetic and summation order per element as hipseg_conv_wgrad with that split count.
+ * hipseg_conv_wgrad_pair_applies: 1 when the pair is taken for the shape (bf16; >= 64 channels, multiples of 64, on all
+ * sides; H, W multiples of 16; the paired grid fills >= 90 % of the CUs), else 0 -> use hipseg_conv_wgrad twice.
+ * `slabs`: max(hipseg_wgrad_workspace_elems(a), hipseg_wgrad_workspace_elems(b)) floats suffice.
+ * replaces: the weight-gradient halves of aten::convolution_backward of both Conv2d of a ConvBlock
+ *           (models/processing_blocks.py:43,46 under autograd). */
+int hipseg_conv_wgrad_pair_applies(int dtype, int CUa0, int CUa1, int CUb, int CV, int B, int H, int W);
+int hipseg_conv_wgrad_pair(int dtype, const void* pa0, int CUa0, const void* pa1, int CUa1, const void* qa, float* dwa,
+                           const void* pb, int CUb, const void* qb, float* dwb, int CV, float* slabs, int B, int H,
+                           int W, hipseg_stream_t stream);
+
 /* ---- BatchNorm2d (train: batch statistics; eval: running statistics) ---------------
  * bn_finalize: reduce the conv epilogue partials -> mean, invstd, scale = gamma*invstd,
  *   shift = beta - mean*scale; running_mean/var updated with momentum (unbiased var) and

@@ -267,6 +267,52 @@ def test_conv3_dgrad_with_bn_backward_sums(hs, case):
     assert float((got.double() - ex).abs().max()) <= 5e-5 * max(float(ex.abs().max()), 1.0)
 
 
+# B, CUa0, CUa1, CUb (= CV), H, W: encoder block (single source), decoder block (dual source), more channel tiles, a
+# pixel grid with fewer tiles than CUs / tiles (the split count is capped)
+# (on 256 CUs: 42 splits x 6 tiles = 252 workgroups + 4 of grid padding; 21 x 12; 10 x 24 = 240; 85 x 3 with the narrow
+# reduction; 2 tiles)
+WGRAD_PAIR_CASES = [(16, 64, 0, 128, 64, 64), (8, 128, 128, 128, 64, 64), (2, 128, 0, 256, 32, 48), (8, 64, 64, 64, 64, 64),
+                    (1, 64, 0, 64, 16, 32)]
+
+
+@pytest.mark.parametrize("case", WGRAD_PAIR_CASES, ids=[str(c) for c in WGRAD_PAIR_CASES])
+def test_wgrad_pair_matches_two_launches(hs, case):
+    """hipseg_conv_wgrad_pair (both 3x3 weight gradients of a ConvBlock in one launch) against two hipseg_conv_wgrad
+    launches (fp32 sums split differently over the pixels) and against autograd's fp32 weight gradient."""
+    B, Ca0, Ca1, Cb, H, W = case
+    L, ops = hs.L, hs.ops
+    td, dt = torch.bfloat16, L.BF16
+    CV = Cb
+    assert L.conv_wgrad_pair_applies(dt, Ca0, Ca1, Cb, CV, B, H, W) == 1
+    xa0 = rnd(T("wp.xa0", (B, Ca0, H, W), -1, 1), td)
+    xa1 = rnd(T("wp.xa1", (B, Ca1, H, W), -1, 1), td) if Ca1 else None
+    xb = rnd(T("wp.xb", (B, Cb, H, W), -1, 1), td)
+    qa = rnd(T("wp.qa", (B, CV, H, W), -1, 1), td)
+    qb = rnd(T("wp.qb", (B, CV, H, W), -1, 1), td)
+    d = {k: (to_dev_nhwc(v, td) if v is not None else None) for k, v in dict(xa0=xa0, xa1=xa1, xb=xb, qa=qa, qb=qb).items()}
+    Ca = Ca0 + Ca1
+    slabs = torch.empty(max(L.wgrad_workspace_elems(L.CONV3, Ca, CV, B, H, W), L.wgrad_workspace_elems(L.CONV3, Cb, CV, B, H, W)),
+                        device="cuda")
+    s = ops._stream()
+    ra, rb = torch.empty(CV, Ca, 3, 3, device="cuda"), torch.empty(CV, Cb, 3, 3, device="cuda")
+    L.conv_wgrad(dt, L.CONV3, ops.ptr(d["xa0"]), Ca0, ops.ptr(d["xa1"]), Ca1, ops.ptr(d["qa"]), CV, ops.ptr(ra), ops.ptr(slabs),
+                 B, H, W, s)
+    L.conv_wgrad(dt, L.CONV3, ops.ptr(d["xb"]), Cb, 0, 0, ops.ptr(d["qb"]), CV, ops.ptr(rb), ops.ptr(slabs), B, H, W, s)
+    ga = torch.full((CV, Ca, 3, 3), float("nan"), device="cuda")
+    gb = torch.full((CV, Cb, 3, 3), float("nan"), device="cuda")
+    slabs.fill_(float("nan"))
+    L.conv_wgrad_pair(dt, ops.ptr(d["xa0"]), Ca0, ops.ptr(d["xa1"]), Ca1, ops.ptr(d["qa"]), ops.ptr(ga), ops.ptr(d["xb"]), Cb,
+                      ops.ptr(d["qb"]), ops.ptr(gb), CV, ops.ptr(slabs), B, H, W, s)
+    torch.cuda.synchronize()
+    for got, ref, x, q in ((ga, ra, torch.cat([xa0, xa1], 1) if Ca1 else xa0, qa), (gb, rb, xb, qb)):
+        assert bool(torch.isfinite(got).all())
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) <= 2e-5 * scale * (B * H * W) ** 0.5 / 16
+        w = torch.zeros(CV, x.shape[1], 3, 3, requires_grad=True)
+        F.conv2d(x, w, None, padding=1).backward(q)
+        assert float((got.cpu() - w.grad).abs().max()) <= 2e-4 * max(1.0, float(w.grad.abs().max()))
+
+
 # B, C0, C1, Cout, H, W: the 1x1 fusion conv of ClipUnetPrompt at training size (dual source 512 + 512 -> 512 at H/8),
 # single source, ragged channel counts / pixel counts
 CONV1_CASES = [(2, 512, 512, 512, 8, 8), (1, 64, 0, 128, 16, 16), (2, 24, 8, 40, 5, 7), (1, 128, 128, 64, 12, 20)]
