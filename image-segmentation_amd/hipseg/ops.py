@@ -307,6 +307,19 @@ def _wgrad(dt, mode, p0, p1, q, dw, B, H, W):
            cv, ptr(dw), ptr(slabs), B, H, W, _stream())
 
 
+def _wgrad_pair(dt, pa0, pa1, qa, dwa, pb, qb, dwb, B, H, W):
+    """both 3x3 weight gradients of a ConvBlock in one launch (hipseg_conv_wgrad_pair; the caller asked
+    L.conv_wgrad_pair_applies).  Timed as ONE entry of the weight-gradient group with the FLOPs of both layers."""
+    ca0 = pa0.shape[1]
+    ca1 = pa1.shape[1] if pa1 is not None else 0
+    cb, cv = pb.shape[1], qa.shape[1]
+    slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, ca0 + ca1, cv, B, H, W), L.wgrad_workspace_elems(L.CONV3, cb, cv, B, H, W)),
+                 dwa.device)
+    key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},CONV3>(+reduce)"
+    _timed(key, 2.0 * B * H * W * (ca0 + ca1 + cb) * cv * 9, L.conv_wgrad_pair, dt, ptr(pa0), ca0, ptr(pa1), ca1, ptr(qa),
+           ptr(dwa), ptr(pb), cb, ptr(qb), ptr(dwb), cv, ptr(slabs), B, H, W, _stream())
+
+
 class _BN:
     """per-layer BatchNorm state of one forward (device vectors of length C)."""
     __slots__ = ("mean", "invstd", "scale", "shift")
@@ -359,17 +372,21 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     return raw, act, bn, wpt
 
 
-def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta):
+def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None):
     """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv); `bias`, `gamma`, `beta` are
-    the conv-bias / BN parameters (for their gradient destinations)."""
+    the conv-bias / BN parameters (for their gradient destinations).  `reduced` = (partial, rows): the reduction's
+    partial rows already exist (written by the data-gradient kernel that produced dy, hipseg_conv3_dgrad_bnstats)."""
     B, C, H, W = raw.shape
     dev = raw.device
     s = _stream()
-    nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
-    partial = _f32(nblk * 2 * C, dev)
     sums = grad_out_pair(beta, gamma)  # [sum g | sum g*xhat] = [dbeta | dgamma]
-    L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
-                    B, H, W, C, int(pool), s)
+    if reduced is not None:
+        partial, nblk = reduced
+    else:
+        nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
+        partial = _f32(nblk * 2 * C, dev)
+        L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
+                        B, H, W, C, int(pool), s)
     # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
     # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8).  The finalize launch writes it.
     dbias = grad_out(bias)
@@ -496,24 +513,43 @@ class ConvBlockFn(torch.autograd.Function):
         s = _stream()
         dout = as_nhwc(dout, raw2.dtype)
         b1, g1, be1, b2, g2, be2 = ctx.small
+        c0 = x0.shape[1]
+        c1 = x1.shape[1] if x1 is not None else 0
+        # same launch sequence as hipseg_convblock_backward (csrc/block.hip): both weight gradients as one paired launch
+        # and the first layer's BatchNorm-backward sums out of the data-gradient epilogue, where the shapes allow
+        pair = bool(L.conv_wgrad_pair_applies(dt, c0, c1, C, C, B, H, W))
         # ---- second conv layer
         draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2)
         dw2 = grad_out(w2)
-        _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
+        if not pair:
+            _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
         if wp2t is None:
             wp2t = _pack_conv(w2, dt, True)
         da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
-        igemm(dt, L.CONV3, draw2, C, None, 0, wp2t, None, da1, C, None, 0, None, B, H, W)
+        rows = L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W)
+        reduced = None
+        if rows:
+            partial = _f32(rows * 2 * C, dev)
+            bn1 = ctx.bn1
+            # (its own timing group: the epilogue adds a read of raw1 per output tile -- the time of the BatchNorm
+            # reduce launch it replaces -- at the same algorithmic FLOPs as the plain data gradient)
+            _timed("conv_igemm<bf16,CONV3,BN128>+bn_bwd_sums", 2.0 * B * H * W * C * C * 9,
+                   L.conv3_dgrad_bnstats, dt, ptr(draw2), C, ptr(wp2t), ptr(da1), C, ptr(raw1), ptr(bn1.mean), ptr(partial),
+                   B, H, W, s)
+            reduced = (partial, rows)
+        else:
+            igemm(dt, L.CONV3, draw2, C, None, 0, wp2t, None, da1, C, None, 0, None, B, H, W)
         # ---- first conv layer
-        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False, b1, g1, be1)
+        draw1, dg1, dbe1, db1 = _bn_relu_bwd(dt, da1, raw1, ctx.bn1, train, False, b1, g1, be1, reduced)
         dw1 = grad_out(w1)
-        _wgrad(dt, L.CONV3, x0, x1, draw1, dw1, B, H, W)
+        if pair:
+            _wgrad_pair(dt, x0, x1, draw1, dw1, a1, draw2, dw2, B, H, W)
+        else:
+            _wgrad(dt, L.CONV3, x0, x1, draw1, dw1, B, H, W)
         dx0 = dx1 = None
         need0 = ctx.needs_input_grad[0]
         need1 = x1 is not None and ctx.needs_input_grad[1]
         if need0 or need1:
-            c0 = x0.shape[1]
-            c1 = x1.shape[1] if x1 is not None else 0
             if wp1t is None:
                 wp1t = _pack_conv(w1, dt, True)
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
