@@ -79,7 +79,12 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
             return rc;
     // data gradient of the second conv; where a kernel with that epilogue takes the shape it also reduces the
     // BatchNorm-backward sums of the first layer (its output IS that layer's dy), saving a pass over da1 and raw1
-    const int fused_rows = hipseg_conv3_dgrad_bnstats_rows(dt, C, C, B, H, W);
+    // (only when its rows fit the `partial` workspace as include/hipseg.h sizes it: the reduce kernels' block counts)
+    int fused_rows = hipseg_conv3_dgrad_bnstats_rows(dt, C, C, B, H, W);
+    {
+        const int n0 = hipseg_bn_bwd_blocks(B, H, W, C, dt, 0), n1 = a->pool ? hipseg_bn_bwd_blocks(B, H, W, C, dt, 1) : 0;
+        if (fused_rows > (n0 > n1 ? n0 : n1)) fused_rows = 0;
+    }
     if (fused_rows) {
         if (int rc = hipseg_conv3_dgrad_bnstats(dt, a->draw2, C, a->wp2t, a->da1, C, a->raw1, a->bn1, a->partial, B, H, W, s))
             return rc;

@@ -231,7 +231,11 @@ int hipseg_colsum(int dtype, const void* x, long npix, int C, float* partial, fl
  *   sums1/2 : float[2 * Cout] = dbeta | dgamma of the two BatchNorm layers
  * forward : x0 (|x1) -> raw1 -> a1 -> raw2 -> out (H/2 x W/2 when pool).  wp1/wp2: packed forward operands.
  * backward: dout -> draw2 -> dw2, da1 -> draw1 -> dw1 [, dx0 | dx1 when need_dx].  wp1t/wp2t: packed data-gradient
- *           operands (hipseg_pack_conv_weight(..., transpose = 1)). */
+ *           operands (hipseg_pack_conv_weight(..., transpose = 1)).  draw1 may be the SAME buffer as draw2 (d(raw2) is
+ *           dead once da1 and dw2 exist); with two distinct buffers the backward runs both weight gradients as one
+ *           paired launch where hipseg_conv_wgrad_pair_applies() says so.  Where hipseg_conv3_dgrad_bnstats_rows()
+ *           is non-zero (and fits `partial`) the first layer's BatchNorm-backward sums come out of the second layer's
+ *           data-gradient kernel. */
 typedef struct hipseg_convblock {
     int32_t dtype, B, H, W, C0, C1, Cout, train, pool, need_dx;
     float eps, momentum;
