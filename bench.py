@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet"])
+    ap.add_argument("--model", default="UNet", choices=["UNet", "LargeUNet", "ClipUnet", "ClipUnetPrompt"],
+                    help="ClipUnetPrompt: the binary model of the reference's scripts/prompt_train.py:55-58 (image + prompt "
+                         "heat map -> 1-channel logits, HybridLossBinary = BCE + Dice); not a BASELINE.json config")
     ap.add_argument("--loop", default=os.environ.get("HIPSEG_BENCH_LOOP", "auto"),
                     choices=["auto", "eager", "graph", "splitgraph", "evgraph"],
                     help="auto: graph for one GPU, evgraph for N > 1.  evgraph: hipGraph(fwd+bwd) with one EXTERNAL "
@@ -396,12 +398,17 @@ def worker(args, world):
     from models.losses import HybridLoss
 
     torch.manual_seed(0)
+    binary = args.model == "ClipUnetPrompt"
     if args.model == "ClipUnet":
         # BASELINE config 5: frozen CLIP ViT-B/32 image tower (random init: the pretrained weights are a network
         # fetch) on PyTorch-ROCm + the HIP U-Net trunk
         os.environ.setdefault("HIPSEG_CLIP_RANDOM_INIT", "1")
         from models.CLIP_models import ClipUnet
         model = ClipUnet().to(dev).train()
+    elif binary:
+        os.environ.setdefault("HIPSEG_CLIP_RANDOM_INIT", "1")
+        from models.prompt_segmentation import ClipUnetPrompt
+        model = ClipUnetPrompt().to(dev).train()
     else:
         model = getattr(un, args.model)().to(dev).train()
     loop = args.loop
@@ -418,7 +425,11 @@ def worker(args, world):
     # smaller cap starts their reduction earlier; xGMI all-reduce latency (~tens of us) is paid 5 times instead of 3
     net = HipDDP(model, overlap=("events" if evg else not split), force_collectives=force,
                  bucket_cap_mb=float(os.environ.get("HIPSEG_BUCKET_MB", "8"))) if ddp else model
-    crit = HybridLoss()
+    if binary:
+        from models.losses import HybridLossBinary
+        crit = HybridLossBinary()
+    else:
+        crit = HybridLoss()
     # the reference's optimizer (models/model_wrappers.py:40-41,124: Adam, lr 1e-3, weight_decay 1e-4)
     trainable = [q for q in model.parameters() if q.requires_grad]
     if args.optimizer == "hip":
@@ -430,13 +441,17 @@ def worker(args, world):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
     t = torch.randint(0, 3, (args.batch, args.size, args.size), generator=g).to(dev)
+    fwd_in = (x,)
+    if binary:  # (image, prompt heat map) -> 1-channel logits against a float {0, 1} mask
+        t = (t > 0).float()
+        fwd_in = (x, torch.rand(args.batch, 1, args.size, args.size, generator=g).to(dev))
 
     # loop body of the reference's TrainingWrapper.train / DistributedTrainingWrapper.train
     # (models/model_wrappers.py:167-177, 968-980), in two halves
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda"):
-            out = (model if (split or evg) else net)(x)  # split / event graphs: the buffer broadcast stays outside
+            out = (model if (split or evg) else net)(*fwd_in)  # split / event graphs: the buffer broadcast stays outside
             loss = crit(out, t)
         scaler.scale(loss).backward()  # HipDDP hooks: per-bucket all-reduce on the comm stream, joined at the end
         if split:
@@ -616,9 +631,11 @@ def worker(args, world):
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.model} 3x{args.size}x{args.size} train step (fwd + CE + bwd + GradScaler/Adam"
-                               f"{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch {args.batch}/GPU, "
-                               f"BASELINE.json configs[{_config_index(args, world)}]",
+        "config": {"workload": f"{args.model} 3x{args.size}x{args.size} train step (fwd + {'BCE+Dice' if binary else 'CE'} + bwd + "
+                               f"GradScaler/Adam{' + bucketed RCCL grad all-reduce' if world > 1 else ''}), batch "
+                               f"{args.batch}/GPU, "
+                               + ("scripts/prompt_train.py:55-58 (not a BASELINE.json config)" if binary
+                                  else f"BASELINE.json configs[{_config_index(args, world)}]"),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "loop": loop_desc[loop_used],
                    "optimizer": "hipseg.optim.Adam (HIP multi-tensor kernel)" if args.optimizer == "hip"
