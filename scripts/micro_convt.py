@@ -18,8 +18,12 @@ for name, B, ci, co, H in LAYERS:
     wp, wpt = ops._pack_convT(w, dt, False), ops._pack_convT(w, dt, True)
     y = ops.nhwc_empty(B, co, 2 * H, 2 * H, td, "cuda")
     dx = ops.nhwc_empty(B, ci, H, H, td, "cuda")
+    dw = torch.empty(ci, co, 2, 2, device="cuda")
+    slabs = ops._f32(L.wgrad_workspace_elems(L.CONVT, co, ci, B, H, H), "cuda")
+    s = torch.cuda.current_stream().cuda_stream
     fns = {"fwd": lambda: ops.igemm(dt, L.CONVT, x, ci, None, 0, wp, b, y, co, None, 0, None, B, H, H),
-           "dgrad": lambda: ops.igemm(dt, L.CONV2S2, dy, co, None, 0, wpt, None, dx, ci, None, 0, None, B, H, H)}
+           "dgrad": lambda: ops.igemm(dt, L.CONV2S2, dy, co, None, 0, wpt, None, dx, ci, None, 0, None, B, H, H),
+           "wgrad": lambda: L.conv_wgrad(dt, L.CONVT, ops.ptr(dy), co, 0, 0, ops.ptr(x), ci, ops.ptr(dw), ops.ptr(slabs), B, H, H, s)}
     for which, fn in fns.items():
         for _ in range(3):
             fn()
