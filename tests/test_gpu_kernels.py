@@ -433,7 +433,10 @@ def test_stem_head(hs, prec, td, dt):
 
 
 @pytest.mark.parametrize("prec,td,dt", DTYPES, ids=[d[0] for d in DTYPES])
-@pytest.mark.parametrize("geo", [(16, 16, 8, 8), (8, 24, 4, 12), (8, 8, 16, 16), (6, 10, 6, 10), (4, 4, 1, 1)])
+@pytest.mark.parametrize("geo", [(16, 16, 8, 8), (8, 24, 4, 12), (8, 8, 16, 16), (6, 10, 6, 10), (4, 4, 1, 1),
+                                 # the production case (dec1: 64 -> 32) and non-integer ratios both ways: the backward
+                                 # gather's candidate window must contain every output pixel that sampled an input pixel
+                                 (64, 64, 32, 32), (33, 47, 12, 20), (12, 20, 33, 47), (31, 17, 30, 16), (5, 7, 64, 2)])
 def test_bilinear(hs, prec, td, dt, geo):
     ops = hs.ops
     Hi, Wi, Ho, Wo = geo
