@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // partial[blk][Cin+1][Cout]: rows 0..Cin-1 = sum dy*x_ci, row Cin = sum dy
 template <typename T, int V>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                        float* __restrict__ partial, int B, int Cin, long HW, int Cout,
-                                                        int CG, int PL, long ppb) {
+                                                        const T* __restrict__ dy2, float* __restrict__ partial, int B,
+                                                        int Cin, long HW, int Cout, int CG, int PL, long ppb) {
     __shared__ float red[2048];
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                     const unsigned pu = (unsigned)p, hw_n = (unsigned)HW;  // 32-bit divide (launch condition)
                     const unsigned n = pu / hw_n, hw = pu - n * hw_n;
                     ldv<T, V>(dy + p * Cout + cg * V, g[u]);
+                    if (dy2) {  // second gradient of the same tensor (the stem output also feeds the last decoder block)
+                        float g2[V];
+                        ldv<T, V>(dy2 + p * Cout + cg * V, g2);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) g[u][e] += g2[e];
+                    }
 #pragma unroll
                     for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = ci < Cin ? x[((size_t)n * Cin + ci) * hw_n + hw] : 0.f;
                 } else {
@@ -529,6 +535,11 @@ extern "C" int hipseg_stem_bwd_blocks(int B, int H, int W) {
 
 extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float* partial, float* dw, float* db, int B,
                                int Cin, int H, int W, int Cout, hipseg_stream_t stream) {
+    return hipseg_stem_bwd2(dtype, x, dy, nullptr, partial, dw, db, B, Cin, H, W, Cout, stream);
+}
+
+extern "C" int hipseg_stem_bwd2(int dtype, const float* x, const void* dy, const void* dy2, float* partial, float* dw,
+                                float* db, int B, int Cin, int H, int W, int Cout, hipseg_stream_t stream) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "stem_bwd: bad dtype");
     HS_REQUIRE(x && dy && partial && dw && db && B > 0 && H > 0 && W > 0, "stem_bwd: bad arguments");
     HS_REQUIRE(Cin >= 1 && Cin <= MAXCIN, "stem_bwd: in_channels %d unsupported (1..%d)", Cin, MAXCIN);
@@ -543,8 +554,8 @@ extern "C" int hipseg_stem_bwd(int dtype, const float* x, const void* dy, float*
     g.ppb = (npix + g.nblk - 1) / g.nblk;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
-        hipLaunchKernelGGL((stem_bwd_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, x, (const T_*)dy, partial, B, Cin,
-                           HW, Cout, g.CG, g.PL, g.ppb);
+        hipLaunchKernelGGL((stem_bwd_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, x, (const T_*)dy, (const T_*)dy2, partial,
+                           B, Cin, HW, Cout, g.CG, g.PL, g.ppb);
     });
     HS_LAUNCH_CHECK("stem_bwd");
     hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3((Cin + 1) * Cout), dim3(64), 0, s, partial, g.nblk, Cin, Cout, dw,

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "hipseg_stem_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_stem_bwd_blocks": (I, [I, I, I]),
     "hipseg_stem_bwd": (I, [I, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_stem_bwd2": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_head_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_head_bwd_blocks": (I, [I, I, I]),
     "hipseg_head_bwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -667,10 +667,14 @@ class BilinearFn(torch.autograd.Function):
 
 
 class StemFn(torch.autograd.Function):
-    """1x1 stem conv on the NCHW fp32 image -> NHWC activations (models/UNet.py:39,62)."""
+    """1x1 stem conv on the NCHW fp32 image -> NHWC activations (models/UNet.py:39,62).
+    `two`: return the activations TWICE (the second an alias of the first).  The U-Nets use the stem output both as the
+    first encoder block's input and as the last decoder block's skip tensor; given one tensor object, autograd sums
+    the two gradients in a pass of its own (read 2, write 1 tensor of the largest activation size) before this
+    backward runs.  With one alias per consumer each gradient arrives on its own and hipseg_stem_bwd2 reads both."""
 
     @staticmethod
-    def forward(ctx, x, w, b, prec):
+    def forward(ctx, x, w, b, prec, two=False):
         B, cin, H, W = x.shape
         cout = w.shape[0]
         td = _tdtype(prec)
@@ -679,21 +683,28 @@ class StemFn(torch.autograd.Function):
         L.stem_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(y), B, cin, H, W, cout, _stream())
         ctx.save_for_backward(x)
         ctx.dt, ctx.wshape, ctx.params = dt, w.shape, (w, b)
-        return y
+        ctx.set_materialize_grads(False)  # an unused alias hands None to backward, not a tensor of zeros
+        return (y, y.detach()) if two else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("hipseg: gradient w.r.t. the input image is not part of the training hot path")
         (x,) = ctx.saved_tensors
         B, cin, H, W = x.shape
         cout = ctx.wshape[0]
-        dy = as_nhwc(dy, _tdtype("bf16" if ctx.dt == L.BF16 else "fp32"))
+        td = _tdtype("bf16" if ctx.dt == L.BF16 else "fp32")
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return None, None, None, None, None
+        dy = as_nhwc(dy, td)
+        dy2 = as_nhwc(dy2, td) if dy2 is not None else None
         nblk = L.stem_bwd_blocks(B, H, W)
         part = _f32(nblk * (cin + 1) * cout, x.device)
         dw, db = grad_out(ctx.params[0]), grad_out(ctx.params[1])
-        L.stem_bwd(ctx.dt, ptr(x), ptr(dy), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
-        return None, dw, db, None
+        L.stem_bwd2(ctx.dt, ptr(x), ptr(dy), ptr(dy2), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
+        return None, dw, db, None, None
 
 
 class HeadFn(torch.autograd.Function):

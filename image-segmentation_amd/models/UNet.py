@@ -7,12 +7,19 @@ from models.processing_blocks import ConvBlock, ConvBlockDownsample, ConvBlockUp
 
 
 
-def _stem(conv, x):
-    """1x1 stem on the NCHW image -> NHWC activations in the active precision."""
+_NO_STEM_ALIAS = bool(__import__("os").environ.get("HIPSEG_NO_STEM_ALIAS"))
+
+
+def _stem(conv, x, two=False):
+    """1x1 stem on the NCHW image -> NHWC activations in the active precision.  `two`: (activations, alias) for the two
+    consumers of the stem output, see ops.StemFn."""
     ops._require_gpu(x)
     if x.shape[1] != conv.in_channels:
         raise ValueError(f"expected {conv.in_channels} input channels, got {x.shape[1]}")
-    return ops.StemFn.apply(x.float().contiguous(), conv.weight, conv.bias, ops.precision())
+    if _NO_STEM_ALIAS and two:  # A/B switch: one tensor for both consumers (autograd sums the gradients)
+        y = ops.StemFn.apply(x.float().contiguous(), conv.weight, conv.bias, ops.precision(), False)
+        return y, y
+    return ops.StemFn.apply(x.float().contiguous(), conv.weight, conv.bias, ops.precision(), two)
 
 
 def _head(conv, x):
@@ -41,8 +48,8 @@ class _UNetBase(nn.Module):
             raise ValueError(f"input must be (B,C,H,W) with H, W divisible by {div}; got {tuple(x.shape)}")
         ops._require_gpu(x)
         ops.prepack(self, ops.precision())  # all conv / ConvT operands of this step, one launch
-        h = _stem(self.input, x)
-        skips = [h]
+        h, h_skip = _stem(self.input, x, two=True)  # one alias per consumer: enc1 below, the last decoder block's skip
+        skips = [h_skip]
         for k in range(1, len(self._enc) + 1):
             h = getattr(self, f"enc{k}")(h)
             skips.append(h)

@@ -69,7 +69,7 @@ class ClipUnetPrompt(nn.Module):
         ops._require_gpu(X)
         clip_features = self.clip_feature_extractor(X)
         ops.prepack(self, ops.precision())  # all 3x3 conv / ConvT operands of this step, one launch
-        inp = _stem(self.input, X)
+        inp, inp_skip = _stem(self.input, X, two=True)  # (an alias per consumer, see ops.StemFn)
         enc1 = self.enc1(inp)
         enc2 = self.enc2(enc1)
         enc3 = self.enc3(enc2)
@@ -80,5 +80,5 @@ class ClipUnetPrompt(nn.Module):
         d = self.dec1(fused, enc3)
         d = self.dec2(d, enc2)
         d = self.dec3(d, enc1)
-        d = self.dec4(d, inp)
+        d = self.dec4(d, inp_skip)
         return self.activation(_head(self.out, d))

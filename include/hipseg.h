@@ -262,6 +262,11 @@ int hipseg_stem_fwd(int dtype, const float* x_nchw, const float* w, const float*
 int hipseg_stem_bwd_blocks(int B, int H, int W);
 int hipseg_stem_bwd(int dtype, const float* x_nchw, const void* dy, float* partial, float* dw,
                     float* db, int B, int Cin, int H, int W, int Cout, hipseg_stream_t stream);
+/* the same with dY = dy + dy2 (dy2 may be NULL): the stem output feeds both the first encoder block and, as the skip
+ * tensor, the last decoder block (models/UNet.py:62,72); autograd would first sum the two gradients in a pass of its
+ * own (3 x the tensor in traffic), here the second one is read beside the first. */
+int hipseg_stem_bwd2(int dtype, const float* x_nchw, const void* dy, const void* dy2, float* partial, float* dw,
+                     float* db, int B, int Cin, int H, int W, int Cout, hipseg_stream_t stream);
 /* head: Conv2d(Cin, Cout<=8, 1) NHWC activations -> NCHW fp32 logits (models/UNet.py:55,73).
  * head_bwd: dX (NHWC, dtype), dW (Cout,Cin), db (Cout) from NCHW fp32 dlogits. */
 int hipseg_head_fwd(int dtype, const void* x, const float* w, const float* b, float* logits_nchw,

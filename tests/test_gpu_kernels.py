@@ -412,6 +412,25 @@ def test_stem_head(hs, prec, td, dt):
     check(yy.detach(), y.detach(), td, what="stem fwd")
     assert (wd.grad.cpu() - w.grad).abs().max() <= 2e-4 * float(w.grad.abs().max())
     assert (bd.grad.cpu() - b.grad).abs().max() <= 2e-4 * float(b.grad.abs().max())
+    # two aliases of the output (the U-Nets: first encoder block + last decoder block's skip): each consumer's gradient
+    # arrives on its own, hipseg_stem_bwd2 reads both -> gradients of y used twice; one alias unused -> the plain result
+    dy2 = rnd(T("s.dy2", (B, 32, H, W)), td)
+    w2 = w.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True)
+    y2 = F.conv2d(x, w2, b2)
+    ((y2 * dy).sum() + (y2 * dy2).sum()).backward()
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    ya, yb = ops.StemFn.apply(x.cuda(), wd, bd, prec, True)
+    assert ya.data_ptr() == yb.data_ptr()
+    ((ya.float() * to_dev_nhwc(dy, td).float()).sum() + (yb.float() * to_dev_nhwc(dy2, td).float()).sum()).backward()
+    torch.cuda.synchronize()
+    assert (wd.grad.cpu() - w2.grad).abs().max() <= 2e-4 * float(w2.grad.abs().max())
+    assert (bd.grad.cpu() - b2.grad).abs().max() <= 2e-4 * float(b2.grad.abs().max())
+    wd.grad = bd.grad = None
+    ya, yb = ops.StemFn.apply(x.cuda(), wd, bd, prec, True)
+    yb.backward(to_dev_nhwc(dy, td))  # (only the second alias is used)
+    torch.cuda.synchronize()
+    assert (wd.grad.cpu() - w.grad).abs().max() <= 2e-4 * float(w.grad.abs().max())
     # head
     for cout in (3, 1):
         hx = rnd(T("h.x", (B, 32, H, W)), td).requires_grad_(True)
