@@ -124,12 +124,12 @@ __device__ __forceinline__ void dma_piece(v4i_t rsrc, unsigned lds_addr, unsigne
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");  // (m0 is written: the compiler must not keep a value of its own there)
 }
 
 // per-lane 64-bit source pointer form (global_load_lds_dwordx4)
 __device__ __forceinline__ void dma_piece_ptr(const void* src, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(src) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(src) : "memory", "m0");
 }
 
 

@@ -93,7 +93,8 @@ class HipDDP(nn.Module):
     last_capture_attempts = None  # attempts the most recent capture_graphs() needed
 
     def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb=25.0, first_bucket_mb=1.0,
-                 broadcast_buffers=True, overlap=True, force_collectives=False, grad_in_bucket=True):
+                 broadcast_buffers=True, overlap=True, force_collectives=False, grad_in_bucket=True,
+                 defer_comm=False, world_size=None):
         """device_ids : accepted for call compatibility with `DDP(model, device_ids=[rank])`
                         (scripts/train_distributed.py:35); the module's own device is used.
         overlap=True : reduce each bucket from autograd hooks during backward on a side HIP stream.  Works in eager
@@ -111,13 +112,26 @@ class HipDDP(nn.Module):
         force_collectives : issue every collective even when the group has ONE rank (RCCL runs them as device-side
                        no-op/copies), so the whole hook -> bucket -> event -> side-stream all-reduce -> join path can
                        be rehearsed and tested on a single-GPU box.
-        grad_in_bucket : let the HIP backward kernels write parameter gradients directly into the bucket slots."""
+        grad_in_bucket : let the HIP backward kernels write parameter gradients directly into the bucket slots.
+        defer_comm     : build everything that needs NO communicator (buckets, slots, hooks, bucket events, the flat
+                       buffer tensor) now and leave the process group to attach(): the step can then be warmed up and
+                       its hipGraphs captured (overlap="events" / overlap=False hold no collective) in a process that
+                       has no c10d / RCCL thread yet; attach() afterwards does the rank-0 broadcasts of the constructor
+                       IN PLACE (captured addresses stay valid).  `world_size` (default: $WORLD_SIZE) tells the hooks
+                       whether there will be anything to reduce."""
         super().__init__()
-        if not dist.is_initialized():
-            raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
+        if defer_comm:
+            if overlap is True:
+                raise ValueError("defer_comm needs overlap='events' or overlap=False: overlap=True issues its collectives "
+                                 "from the backward hooks and cannot run without a process group")
+            self.world = int(world_size if world_size is not None else os.environ.get("WORLD_SIZE", "1"))
+        else:
+            if not dist.is_initialized():
+                raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
+            self.world = dist.get_world_size(process_group)
         self.module = module
         self.pg = process_group
-        self.world = dist.get_world_size(process_group)
+        self._comm_ready = False
         self.active = self.world > 1 or bool(force_collectives)
         self.stats = {"buckets_reduced": 0, "comm_stream_collectives": 0, "hook_calls": 0, "hook_copies": 0,
                       "zero_filled_slots": 0}
@@ -146,9 +160,7 @@ class HipDDP(nn.Module):
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._cb_queued = False
         self._require_sync = True
-        # ---- initial state broadcast (rank 0 wins), as DDP's constructor does
         with torch.no_grad():
-            self._bcast([p.data for p in module.parameters()])
             # floating-point buffers (BN running statistics) are re-pointed into ONE flat tensor so the
             # per-forward DDP buffer broadcast is a single collective with no gather/scatter copies
             fbufs = [b for b in module.buffers() if b.is_floating_point()]
@@ -160,10 +172,6 @@ class HipDDP(nn.Module):
                     b.data = flat[o:o + b.numel()].view_as(b)
                     o += b.numel()
                 self._flat_buffers = flat
-                dist.broadcast(flat, 0, group=self.pg)
-            for b in module.buffers():
-                if not b.is_floating_point():
-                    dist.broadcast(b, 0, group=self.pg)
         self.overlap = overlap
         self.events_mode = overlap == "events"
         self._order_building, self._ready_order = [], []
@@ -190,6 +198,35 @@ class HipDDP(nn.Module):
                     p._hipseg_slot = (b.flat, o, self._taken)
                     self._slotted.append(p)
         self._graph_task = None
+        if not defer_comm:
+            self.attach(process_group)
+
+    def attach(self, process_group=None, extra_state=()):
+        """Bind the reducer to the (now initialised) process group and do what DDP's constructor does: parameters and
+        buffers take rank 0's values.  Everything is written IN PLACE, so hipGraphs captured before attach() keep
+        pointing at live memory.  `extra_state`: further tensors that must start identical on every rank when local
+        steps ran before attach() (optimizer moments / step counters, GradScaler scale) -- broadcast the same way."""
+        if self._comm_ready:
+            raise RuntimeError("HipDDP.attach() called twice")
+        if not dist.is_initialized():
+            raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
+        self.pg = process_group
+        world = dist.get_world_size(process_group)
+        if world != self.world:
+            raise RuntimeError(f"HipDDP was prepared for world size {self.world}, the process group has {world}")
+        with torch.no_grad():
+            self._bcast([p.data for p in self.module.parameters()])
+            if self._flat_buffers is not None:
+                dist.broadcast(self._flat_buffers, 0, group=self.pg)
+            for b in self.module.buffers():
+                if not b.is_floating_point():
+                    dist.broadcast(b, 0, group=self.pg)
+            self._bcast([t for t in extra_state if t.is_floating_point()])
+            for t in extra_state:
+                if not t.is_floating_point():
+                    dist.broadcast(t, 0, group=self.pg)
+        self._comm_ready = True
+        return self
 
     @staticmethod
     def watchdog_idle(timeout=5.0):
@@ -248,12 +285,19 @@ class HipDDP(nn.Module):
 
     @staticmethod
     def graph_capture(graph, stream=None, pool=None):
-        """THE capture recipe for a process with a live process group (bench.py and the tests use this one helper):
-        quiesce_before_capture(), then capture in "thread_local" error mode -- other threads of the process (torch's
-        RCCL watchdog, RCCL's own helpers) may call the HIP runtime while we capture without invalidating the capture;
-        kernels launched by the autograd thread on the capturing stream are captured in either mode."""
-        HipDDP.quiesce_before_capture()
-        kw = {"capture_error_mode": "thread_local"}
+        """THE capture recipe (bench.py and the tests use this one helper).
+        No process group yet (HipDDP(defer_comm=True): the recommended order -- capture first, communicator after):
+        the plain `torch.cuda.graph` capture of the single-GPU path; the process has no c10d / RCCL thread.
+        With a live process group (graphs that HOLD collectives, overlap=True): quiesce_before_capture(), then capture
+        in "thread_local" error mode -- other threads of the process (torch's RCCL watchdog, RCCL's own helpers) may
+        call the HIP runtime while we capture; kernels launched by the autograd thread on the capturing stream are
+        captured in either mode."""
+        kw = {}
+        if dist.is_available() and dist.is_initialized():
+            HipDDP.quiesce_before_capture()
+            kw["capture_error_mode"] = "thread_local"
+        else:
+            HipDDP.last_quiesce = "no process group yet"
         if stream is not None:
             kw["stream"] = stream
         if pool is not None:
@@ -261,15 +305,18 @@ class HipDDP(nn.Module):
         return torch.cuda.graph(graph, **kw)
 
     @staticmethod
-    def capture_graphs(fns, stream=None, reducer=None, attempts=3):
+    def capture_graphs(fns, stream=None, reducer=None, attempts=2):
         """Capture each callable of `fns` into its own hipGraph (later ones allocate from the first one's pool) with
-        graph_capture(), and RETRY a failed capture a bounded number of times.  Returns (graphs, results).
-        Why a retry: with a process group alive, a capture is occasionally invalidated before its FIRST kernel launch
-        (hipErrorStreamCaptureInvalidated reported by that launch; seen in about 1 of 5 runs of the event-graph test
-        in rounds 2 and 3, also with the watchdog's work list observably empty and thread_local capture mode -- the
-        trigger inside the HIP runtime / RCCL threads is not identified).  A capture executes nothing, so a failed one
-        leaves no device-side effect; the reducer's per-backward state is re-armed (reset()) and fresh graph objects
-        are used.  The attempt count is reported (`last_capture_attempts`)."""
+        graph_capture().  Returns (graphs, results); `last_capture_attempts` says how many attempts it took.
+        History: with a process group ALIVE, a capture was occasionally invalidated before its FIRST kernel launch
+        (hipErrorStreamCaptureInvalidated reported by that launch, ~1 run in 5 of the event-graph test in rounds 2-3,
+        with the watchdog's work list observably empty and thread_local capture mode): the invalidation came from a
+        thread other than the capturing one, and the only other threads of those processes were c10d's (watchdog,
+        heartbeat monitor, store) and RCCL's.  Since round 4 the event-graph / split-graph paths capture BEFORE the
+        process group exists (defer_comm), so those threads are not there.  The retry stays as a guard and is LOUD:
+        stderr line, `last_capture_attempts` > 1 in the bench JSON, and tests/test_gpu_ddp.py fails on it.
+        A retry is only sound for graphs WITHOUT collectives (a rank that re-captured RCCL calls its peers captured
+        once would desynchronise the communicator): pass attempts=1 for those."""
         last = None
         for attempt in range(attempts):
             graphs, outs, pool = [], [], None
@@ -286,7 +333,7 @@ class HipDDP(nn.Module):
                 last = e
                 import sys
 
-                print(f"[HipDDP] hipGraph capture attempt {attempt + 1}/{attempts} failed: {e!r}"[:400], file=sys.stderr,
+                print(f"[HipDDP] hipGraph capture attempt {attempt + 1}/{attempts} FAILED: {e!r}"[:400], file=sys.stderr,
                       flush=True)
                 graphs = outs = None
                 try:
@@ -382,6 +429,8 @@ class HipDDP(nn.Module):
             self._launch(b)
 
     def _launch(self, b):
+        if not self.events_mode and not self._comm_ready:
+            raise RuntimeError("HipDDP(defer_comm=True): attach() the process group before a backward that reduces")
         if self.events_mode:  # mark the point; allreduce_on_events() issues the collective behind it
             self._events.record(b.ext_ev, self.device)
             self._order_building.append(b)
@@ -441,8 +490,9 @@ class HipDDP(nn.Module):
             torch._foreach_copy_(views, grads)
 
     def allreduce_packed(self):
-        """average the flat buckets over ranks on the current stream and point .grad at the reduced views."""
-        if self.active:
+        """average the flat buckets over ranks on the current stream and point .grad at the reduced views.
+        (Before attach(): a local step -- nothing to average with.)"""
+        if self.active and self._comm_ready:
             for b in self.buckets:
                 self.stats["buckets_reduced"] += 1
                 if self.on_gpu:
@@ -459,6 +509,8 @@ class HipDDP(nn.Module):
         if not self.events_mode:
             raise RuntimeError('allreduce_on_events() belongs to HipDDP(overlap="events")')
         if not self.active or not self._ready_order or not self._require_sync:  # (inside no_sync(): nothing to reduce)
+            return
+        if not self._comm_ready:  # defer_comm: local warm-up / capture steps before attach()
             return
         comm = self.comm_stream
         for b in self._ready_order:
@@ -503,7 +555,7 @@ class HipDDP(nn.Module):
         self.allreduce_packed()
 
     def broadcast_buffers_now(self):
-        if self.broadcast_buffers and self.active and self._flat_buffers is not None:
+        if self.broadcast_buffers and self.active and self._comm_ready and self._flat_buffers is not None:
             dist.broadcast(self._flat_buffers, 0, group=self.pg)
 
     # ------------------------------------------------------------------ forward side

@@ -120,9 +120,11 @@ def grad_out_pair(first, second):
 
 
 # ---------------------------------------------------------------------------------------------
-# optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every MFMA kernel
-# launch is bracketed by HIP events on the launch stream and recorded as
-# (kernel key, algorithmic FLOPs, event0, event1).  None (default) = zero overhead.
+# optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every kernel launch of the
+# convolution / BatchNorm / stem / head / loss / resize groups is bracketed by HIP events on the launch stream and
+# recorded as (kernel key, algorithmic FLOPs, algorithmic HBM bytes, event0, event1) -- FLOPs for the MFMA-bound
+# groups, bytes (every operand read once, every result written once) for the HBM-bound ones,
+# both for the convolutions that sit between the two rooflines.  None (default) = zero overhead.
 PROFILE = None
 _TAPS = {L.CONV3: 9, L.CONV1: 1, L.CONV2S2: 4, L.CONVT: 1}
 _MODE_NAME = {L.CONV3: "CONV3", L.CONV1: "CONV1", L.CONV2S2: "CONV2S2", L.CONVT: "CONVT"}
@@ -131,7 +133,7 @@ _MODE_NAME = {L.CONV3: "CONV3", L.CONV1: "CONV1", L.CONV2S2: "CONV2S2", L.CONVT:
 _EVENT_POOL = []  # timing events are created once: building two per launch costs the eager profiling loop ~10 us each
 
 
-def _timed(key, flops, fn, *args):
+def _timed(key, flops, fn, *args, nbytes=0.0):
     if PROFILE is None:
         return fn(*args)
     i = 2 * len(PROFILE)
@@ -141,7 +143,18 @@ def _timed(key, flops, fn, *args):
     e0.record()
     fn(*args)
     e1.record()
-    PROFILE.append((key, flops, e0, e1))
+    PROFILE.append((key, flops, nbytes, e0, e1))
+
+
+def _hbm(key, nbytes, fn, *args):
+    """an HBM-bound launch: timed (when profiling) against its algorithmic bytes"""
+    if PROFILE is None:
+        return fn(*args)
+    _timed("hbm:" + key, 0.0, fn, *args, nbytes=float(nbytes))
+
+
+def _esz(dt):
+    return 2 if dt == L.BF16 else 4
 
 
 def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H, W):
@@ -154,8 +167,9 @@ def igemm(dt, mode, in0, c0, in1, c1, wp, bias, out0, n0, out1, n1, stats, B, H,
     bn = 128 if N > 64 else (64 if N > 32 else 32)
     key = f"conv_igemm<{'bf16' if dt == L.BF16 else 'f32'},{_MODE_NAME[mode]},BN{bn}>"
     flops = 2.0 * B * H * W * N * (c0 + c1) * _TAPS[mode]
+    nbytes = float(B * H * W) * (c0 + c1 + N) * _esz(dt)  # input read once + output written once (CONVT: 4 Cout per pixel)
     _timed(key, flops, L.conv_igemm, dt, mode, ptr(in0), c0, ptr(in1), c1, ptr(wp), ptr(bias), ptr(out0), n0,
-           ptr(out1), n1, ptr(stats), B, H, W, _stream())
+           ptr(out1), n1, ptr(stats), B, H, W, _stream(), nbytes=nbytes)
 
 
 # ---- packed MFMA operands of the weights.  A model packs ALL its conv / ConvT weights with one launch at the start of
@@ -303,8 +317,10 @@ def _wgrad(dt, mode, p0, p1, q, dw, B, H, W):
     slabs = _f32(L.wgrad_workspace_elems(mode, cu0 + cu1, cv, B, H, W), dw.device)
     nt = 9 if mode == L.CONV3 else (4 if mode == L.CONVT else 1)
     key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},{_MODE_NAME[mode]}>(+reduce)"
+    # bytes: both operands read once (CONVT: p = dy has 4 output pixels of cu0 channels per input pixel)
+    nbytes = float(B * H * W) * ((4 if mode == L.CONVT else 1) * (cu0 + cu1) + cv) * _esz(dt)
     _timed(key, 2.0 * B * H * W * (cu0 + cu1) * cv * nt, L.conv_wgrad, dt, mode, ptr(p0), cu0, ptr(p1), cu1, ptr(q),
-           cv, ptr(dw), ptr(slabs), B, H, W, _stream())
+           cv, ptr(dw), ptr(slabs), B, H, W, _stream(), nbytes=nbytes)
 
 
 def _wgrad_pair(dt, pa0, pa1, qa, dwa, pb, qb, dwb, B, H, W):
@@ -317,7 +333,8 @@ def _wgrad_pair(dt, pa0, pa1, qa, dwa, pb, qb, dwb, B, H, W):
                  dwa.device)
     key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},CONV3>(+reduce)"
     _timed(key, 2.0 * B * H * W * (ca0 + ca1 + cb) * cv * 9, L.conv_wgrad_pair, dt, ptr(pa0), ca0, ptr(pa1), ca1, ptr(qa),
-           ptr(dwa), ptr(pb), cb, ptr(qb), ptr(dwb), cv, ptr(slabs), B, H, W, _stream())
+           ptr(dwa), ptr(pb), cb, ptr(qb), ptr(dwb), cv, ptr(slabs), B, H, W, _stream(),
+           nbytes=float(B * H * W) * (ca0 + ca1 + cb + 2 * cv) * _esz(dt))
 
 
 class _BN:
@@ -368,7 +385,8 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
                          ptr(bn.scale), ptr(bn.shift), s)
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     act = nhwc_empty(B, cout, Ho, Wo, x0.dtype, dev)
-    L.bn_relu_apply(dt, ptr(raw), ptr(bn.scale), ptr(bn.shift), ptr(act), B, H, W, cout, int(pool), s)
+    _hbm("bn_relu_apply" + ("+pool" if pool else ""), B * H * W * cout * _esz(dt) * (1.25 if pool else 2.0),
+         L.bn_relu_apply, dt, ptr(raw), ptr(bn.scale), ptr(bn.shift), ptr(act), B, H, W, cout, int(pool), s)
     return raw, act, bn, wpt
 
 
@@ -385,15 +403,17 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None):
     else:
         nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
         partial = _f32(nblk * 2 * C, dev)
-        L.bn_bwd_reduce(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
-                        B, H, W, C, int(pool), s)
+        _hbm("bn_bwd_reduce" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * (1.25 if pool else 2.0),
+             L.bn_bwd_reduce, dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
+             B, H, W, C, int(pool), s)
     # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
     # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8).  The finalize launch writes it.
     dbias = grad_out(bias)
     L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), ptr(dbias) if train else 0, s)
     draw = nhwc_empty(B, C, H, W, raw.dtype, dev)
-    L.bn_bwd_apply(dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
-                   float(B * H * W), 0 if train else 1, ptr(draw), 0, B, H, W, C, int(pool), s)
+    _hbm("bn_bwd_apply" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * (2.25 if pool else 3.0),
+         L.bn_bwd_apply, dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
+         float(B * H * W), 0 if train else 1, ptr(draw), 0, B, H, W, C, int(pool), s)
     if not train:
         npix = B * H * W
         part = _f32(L.colsum_blocks(npix, C, dt) * C, dev)
@@ -587,7 +607,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         npix = B * 4 * H * W
         part = _f32(L.colsum_blocks(npix, cout, dt) * cout, dev)
         db = grad_out(ctx.bias)
-        L.colsum(dt, ptr(dy), npix, cout, ptr(part), ptr(db), s)
+        _hbm("colsum(convT bias)", npix * cout * _esz(dt), L.colsum, dt, ptr(dy), npix, cout, ptr(part), ptr(db), s)
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_convT(w, dt, True)
@@ -653,7 +673,8 @@ class BilinearFn(torch.autograd.Function):
         dt = _dt(x)
         B, C, Hi, Wi = x.shape
         y = nhwc_empty(B, C, Ho, Wo, x.dtype, x.device)
-        L.bilinear_fwd(dt, ptr(x), ptr(y), B, Hi, Wi, Ho, Wo, C, _stream())
+        _hbm("bilinear_fwd", B * C * (Hi * Wi + Ho * Wo) * _esz(dt), L.bilinear_fwd, dt, ptr(x), ptr(y), B, Hi, Wi, Ho, Wo, C,
+             _stream())
         ctx.geo = (dt, B, C, Hi, Wi, Ho, Wo)
         return y
 
@@ -662,7 +683,8 @@ class BilinearFn(torch.autograd.Function):
         dt, B, C, Hi, Wi, Ho, Wo = ctx.geo
         dy = as_nhwc(dy, _tdtype("bf16" if dt == L.BF16 else "fp32"))
         dx = nhwc_empty(B, C, Hi, Wi, dy.dtype, dy.device)
-        L.bilinear_bwd(dt, ptr(dy), ptr(dx), B, Hi, Wi, Ho, Wo, C, _stream())
+        _hbm("bilinear_bwd", B * C * (Hi * Wi + Ho * Wo) * _esz(dt), L.bilinear_bwd, dt, ptr(dy), ptr(dx), B, Hi, Wi, Ho, Wo, C,
+             _stream())
         return dx, None, None
 
 
@@ -680,7 +702,8 @@ class StemFn(torch.autograd.Function):
         td = _tdtype(prec)
         dt = L.BF16 if prec == "bf16" else L.F32
         y = nhwc_empty(B, cout, H, W, td, x.device)
-        L.stem_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(y), B, cin, H, W, cout, _stream())
+        _hbm("stem_fwd", B * H * W * (cin * 4 + cout * _esz(dt)), L.stem_fwd, dt, ptr(x), ptr(w), ptr(b), ptr(y), B, cin, H, W,
+             cout, _stream())
         ctx.save_for_backward(x)
         ctx.dt, ctx.wshape, ctx.params = dt, w.shape, (w, b)
         ctx.set_materialize_grads(False)  # an unused alias hands None to backward, not a tensor of zeros
@@ -703,7 +726,8 @@ class StemFn(torch.autograd.Function):
         nblk = L.stem_bwd_blocks(B, H, W)
         part = _f32(nblk * (cin + 1) * cout, x.device)
         dw, db = grad_out(ctx.params[0]), grad_out(ctx.params[1])
-        L.stem_bwd2(ctx.dt, ptr(x), ptr(dy), ptr(dy2), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
+        _hbm("stem_bwd", B * H * W * (cin * 4 + (2 if dy2 is not None else 1) * cout * _esz(ctx.dt)), L.stem_bwd2, ctx.dt,
+             ptr(x), ptr(dy), ptr(dy2), ptr(part), ptr(dw), ptr(db), B, cin, H, W, cout, _stream())
         return None, dw, db, None, None
 
 
@@ -716,7 +740,8 @@ class HeadFn(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = w.shape[0]
         logits = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-        L.head_fwd(dt, ptr(x), ptr(w), ptr(b), ptr(logits), B, H, W, cin, cout, _stream())
+        _hbm("head_fwd", B * H * W * (cin * _esz(dt) + cout * 4), L.head_fwd, dt, ptr(x), ptr(w), ptr(b), ptr(logits), B, H, W,
+             cin, cout, _stream())
         ctx.save_for_backward(x, w)
         ctx.dt, ctx.bias = dt, b
         return logits
@@ -731,7 +756,8 @@ class HeadFn(torch.autograd.Function):
         part = _f32(nblk * cout * (cin + 1), x.device)
         dx = nhwc_empty(B, cin, H, W, x.dtype, x.device)
         dw, db = grad_out(w), grad_out(ctx.bias)
-        L.head_bwd(ctx.dt, ptr(x), ptr(dl), ptr(w), ptr(dx), ptr(part), ptr(dw), ptr(db), B, H, W, cin, cout, _stream())
+        _hbm("head_bwd", B * H * W * (2 * cin * _esz(ctx.dt) + cout * 4), L.head_bwd, ctx.dt, ptr(x), ptr(dl), ptr(w), ptr(dx),
+             ptr(part), ptr(dw), ptr(db), B, H, W, cin, cout, _stream())
         return dx, dw, db
 
 
@@ -744,7 +770,7 @@ class CrossEntropyFn(torch.autograd.Function):
         HW = logits[0, 0].numel()
         part = _f32(L.loss_blocks(B * HW) * 2, logits.device)
         loss = _f32(2, logits.device)
-        L.ce_fwd(ptr(logits), ptr(target), ptr(part), ptr(loss), B, C, HW, _stream())
+        _hbm("ce_fwd", B * HW * (C * 4 + 8), L.ce_fwd, ptr(logits), ptr(target), ptr(part), ptr(loss), B, C, HW, _stream())
         ctx.save_for_backward(logits, target, loss)
         return loss[0]
 
@@ -755,7 +781,8 @@ class CrossEntropyFn(torch.autograd.Function):
         HW = logits[0, 0].numel()
         gs = g.reshape(1).float().contiguous()
         dl = torch.empty_like(logits)
-        L.ce_bwd(ptr(logits), ptr(target), ptr(gs), ptr(loss), ptr(dl), B, C, HW, _stream())
+        _hbm("ce_bwd", B * HW * (2 * C * 4 + 8), L.ce_bwd, ptr(logits), ptr(target), ptr(gs), ptr(loss), ptr(dl), B, C, HW,
+             _stream())
         return dl, None
 
 

@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib as L
+from . import ops as _ops
 from .ops import _require_gpu, _stream, ptr
 
 
@@ -95,11 +96,12 @@ class Adam(torch.optim.Optimizer):
                 continue
             host = self._table(st, active)
             b1, b2 = group["betas"]
-            L.adam_step(ctypes.addressof(host), len(active), ptr(st["counter"]),
-                        ptr(found_inf.float() if found_inf is not None else None),
-                        ptr(grad_scale.float() if grad_scale is not None else None),
-                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                        _stream())
+            # (4 reads + 3 writes of 4 bytes per parameter: weight, gradient, two moments)
+            _ops._hbm("adam_step", 28 * sum(p.numel() for p in active), L.adam_step, ctypes.addressof(host), len(active),
+                      ptr(st["counter"]), ptr(found_inf.float() if found_inf is not None else None),
+                      ptr(grad_scale.float() if grad_scale is not None else None),
+                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                      _stream())
             # the kernel wrote the parameters through raw pointers: tell autograd (saved-tensor checks, the packed-weight
             # cache and anything else keyed on ._version must see an in-place update, as after torch.optim.Adam.step)
             torch.autograd.graph.increment_version(active)
@@ -137,6 +139,16 @@ class Adam(torch.optim.Optimizer):
             steps = [int(self.state[p]["step"]) for p in group["params"] if "step" in self.state.get(p, {})]
             if steps:
                 self._loaded_steps[gi] = max(steps)
+
+    def device_state(self):
+        """every device tensor of the optimizer state (flat moments, step counters): what a data-parallel wrapper
+        broadcasts from rank 0 when local steps ran before the replicas were tied together (HipDDP.attach)."""
+        out = []
+        for gi, group in enumerate(self.param_groups):
+            if group["params"]:
+                st = self._group_state(gi, group)
+                out += [st["flat"][0], st["flat"][1], st["counter"]]
+        return out
 
     def step_count(self, group=0):
         """number of applied (non-skipped) steps of a group (host sync).  The count is PER GROUP (one device counter),

@@ -115,8 +115,12 @@ def case_overlapped_allreduce_captured_in_one_hipgraph(pg):
 
         # the ONE capture recipe bench.py uses too: observable watchdog drain + thread_local capture error mode + a
         # bounded retry of an invalidated capture (HipDDP.capture_graphs)
+        # (collectives INSIDE the capture need the communicator first: the thread_local + watchdog-drain recipe; a retry
+        # here is reported to the pytest side, which turns it into an xfail -- visible, never silently green)
         (graph,), (static_loss,) = HipDDP.capture_graphs([captured_step], stream=s, reducer=ddp)
         print("capture attempts:", HipDDP.last_capture_attempts, flush=True)
+        if HipDDP.last_capture_attempts != 1:
+            print("CAPTURE_RETRIED", HipDDP.last_capture_attempts, flush=True)
         assert ddp.stats["comm_stream_collectives"] - n0[0] == len(ddp.buckets)  # captured, not skipped
         # capture only records; replays are steps 3, 4, 5
         for _ in range(3):
@@ -159,6 +163,12 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
         scaler.step(opt)
         scaler.update()
 
+    import torch.distributed as dist
+
+    # the ORDER bench.py --gpus N uses (round 4): reducer prepared, step warmed up and BOTH graphs captured while the
+    # process has no process group and no RCCL communicator (none of their threads exists: the capture is the
+    # single-GPU one); only then init_process_group + attach()
+    assert not dist.is_initialized()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -168,24 +178,18 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
             ref_losses.append(float(fwd_bwd(m0, o0, sc0)))
             opt_step(o0, sc0)
         m1, o1, sc1 = make()
-        ddp = HipDDP(m1, overlap="events", force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0)
+        ddp = HipDDP(m1, overlap="events", force_collectives=True, first_bucket_mb=0.05, bucket_cap_mb=4.0,
+                     defer_comm=True, world_size=1)
         nb = len(ddp.buckets)
         assert nb >= 4 and all(b.ext_ev for b in ddp.buckets)
         losses = []
-        for _ in range(3):  # eager warm-up through the same code path (plain event records)
+        for _ in range(3):  # eager LOCAL warm-up through the same code path (plain event records, nothing to reduce yet)
             ddp.broadcast_buffers_now()
             losses.append(float(fwd_bwd(m1, o1, sc1)))
             ddp.allreduce_on_events()
             opt_step(o1, sc1)
-        assert ddp.stats["event_records"] == 3 * nb and ddp.stats["comm_stream_collectives"] == 3 * nb
+        assert ddp.stats["event_records"] == 3 * nb and ddp.stats["comm_stream_collectives"] == 0
         assert ddp.stats["hook_copies"] == 0
-        # (the RCCL watchdog thread must have retired the eager warm-up collectives before ANY capture starts: its
-        # hipEventQuery during a capture trips over events of the capturing stream.  HipDDP.graph_capture waits until
-        # the watchdog's work list is observably empty and captures in thread_local mode -- the recipe of bench.py)
-        how = HipDDP.quiesce_before_capture()
-        print("quiesce:", how, flush=True)
-        # ("retired": the flight recorder showed the watchdog's work list empty; "sleep": not observable on this build)
-        assert how in ("retired", "sleep")
         c0 = ddp.stats["comm_stream_collectives"]
         ev0 = [0]
 
@@ -194,14 +198,22 @@ def case_event_graph_eager_allreduce_behind_external_events(pg):
             return fwd_bwd(m1, o1, sc1)
 
         (ga, gb), (static_loss, _) = HipDDP.capture_graphs([cap_fwd_bwd, lambda: opt_step(o1, sc1)], stream=s, reducer=ddp)
-        print("capture attempts:", HipDDP.last_capture_attempts, flush=True)
+        print("capture attempts:", HipDDP.last_capture_attempts, "fence:", HipDDP.last_quiesce, flush=True)
+        # a retried capture may NOT pass silently: this path must capture first time
+        assert HipDDP.last_capture_attempts == 1, f"hipGraph capture needed {HipDDP.last_capture_attempts} attempts"
+        assert HipDDP.last_quiesce == "no process group yet"
         assert ddp.stats["event_records"] - ev0[0] == nb       # one external record node per bucket in the graph
         assert ddp.stats["comm_stream_collectives"] == c0      # and NO collective inside the capture
         assert [b for b in ddp._ready_order] and len(ddp._ready_order) == nb
+        # NOW the communicator; attach() broadcasts parameters / buffers / optimizer + GradScaler state in place
+        torch.cuda.synchronize()
+        pg()
+        ptrs = [p.data_ptr() for p in m1.parameters()]
+        ddp.attach(extra_state=list(o1.device_state()) + [sc1._scale, sc1._growth_tracker])
+        assert ptrs == [p.data_ptr() for p in m1.parameters()]
+        c0 = ddp.stats["comm_stream_collectives"]
         # (with ONE rank the all-reduce is an identity, so a collective that ran too early would go unnoticed in the
         # results: a spy snapshots every bucket on the communication stream immediately before its collective)
-        import torch.distributed as dist
-
         real_all_reduce, snaps = dist.all_reduce, []
 
         def spy(tensor, *a, **k):
@@ -360,10 +372,15 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     from hipseg.ddp import HipDDP as _H
 
-    _H.enable_watchdog_trace()
-    dist.init_process_group("nccl", init_method="env://", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    def init_pg():
+        _H.enable_watchdog_trace()
+        dist.init_process_group("nccl", init_method="env://", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+    deferred = name in ("event_graph_eager_allreduce_behind_external_events",)  # creates the group itself, after capture
+    if not deferred:
+        init_pg()
     try:
-        CASES[name](dist)
+        CASES[name](init_pg if deferred else dist)
     except BaseException:  # print at once: the watchdog may abort the process before a normal unwind finishes
         traceback.print_exc()
         sys.stderr.flush()

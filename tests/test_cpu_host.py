@@ -151,8 +151,70 @@ import os, sys
 sys.path[:0] = [{root!r}, os.path.join({root!r}, "image-segmentation_amd")]
 import torch, torch.distributed as dist, torch.nn as nn
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
 from hipseg.ddp import HipDDP
+# ---- defer_comm (the order bench.py --gpus N uses): reducer built, local steps run -- and on a GPU the hipGraphs
+# captured -- BEFORE any process group exists; attach() then ties the replicas together in place
+assert not dist.is_initialized()
+torch.manual_seed(300 + rank)
+netd = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1))
+ddpd = HipDDP(netd, overlap="events", defer_comm=True, world_size=world, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+ptrs = [p.data_ptr() for p in netd.parameters()] + [b.data_ptr() for b in netd.buffers()]
+mom = torch.full((5,), float(rank + 1)); cnt = torch.tensor([rank + 3], dtype=torch.int32)   # "optimizer state"
+xd = torch.rand(2, 3, 8, 8)
+for it in range(2):                                   # local warm-up steps: hooks fire, nothing is reduced
+    ddpd.zero_grad(set_to_none=True)
+    ddpd(xd).square().mean().backward()
+    g_local = [p.grad.detach().clone() for p in netd.parameters()]
+    ddpd.broadcast_buffers_now(); ddpd.allreduce_on_events()
+    assert ddpd.stats["buckets_reduced"] == 0
+    assert all(torch.equal(p.grad, g) for p, g in zip(netd.parameters(), g_local))
+    with torch.no_grad():
+        for p in netd.parameters():
+            p.add_(p.grad, alpha=-0.1 * (rank + 1))   # replicas drift apart
+assert sorted(ddpd.ready_order()) == list(range(len(ddpd.buckets)))
+try:
+    HipDDP(nn.Linear(2, 2), defer_comm=True, world_size=world)        # overlap=True cannot be deferred
+    raise SystemExit("defer_comm with overlap=True was accepted")
+except ValueError:
+    pass
+dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+ddpd.attach(extra_state=[mom, cnt])
+assert ptrs == [p.data_ptr() for p in netd.parameters()] + [b.data_ptr() for b in netd.buffers()]   # in place
+assert torch.equal(mom, torch.full((5,), 1.0)) and int(cnt) == 3      # rank 0's state everywhere
+chk = torch.cat([p.detach().reshape(-1) for p in netd.parameters()] + [netd[1].running_mean, netd[1].running_var])
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert torch.equal(lo, hi)
+try:
+    ddpd.attach()
+    raise SystemExit("second attach() was accepted")
+except RuntimeError:
+    pass
+torch.manual_seed(7)
+xsd = torch.rand(world, 2, 3, 8, 8)
+ddpd.zero_grad(set_to_none=True)
+ddpd(xsd[rank]).square().mean().backward()
+g_local = [p.grad.detach().clone() for p in netd.parameters()]
+ddpd.allreduce_on_events()
+assert ddpd.stats["buckets_reduced"] == len(ddpd.buckets)
+for p, g in zip(netd.parameters(), g_local):
+    ref = g.clone(); dist.all_reduce(ref); ref /= world
+    assert torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-8)
+ddpd.remove_hooks()
+# ---- bench.py's replica check: bit-identical replicas pass, ONE diverged rank (or a NaN on one rank) fails on EVERY rank
+import bench
+ok, gap = bench.replicas_in_sync(list(netd.parameters()), dist)
+assert ok and gap == 0.0
+with torch.no_grad():
+    if rank == world - 1:
+        netd[0].weight[0, 0, 0, 0] += 1e-6
+ok, gap = bench.replicas_in_sync(list(netd.parameters()), dist)
+assert not ok and gap > 0.0, (ok, gap)
+with torch.no_grad():
+    if rank == world - 1:
+        netd[0].weight[0, 0, 0, 0] = float("nan")
+ok, gap = bench.replicas_in_sync(list(netd.parameters()), dist)
+assert not ok and gap != gap
 torch.manual_seed(100 + rank)                      # different init per rank: rank 0 must win
 net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 1))
 ddp = HipDDP(net, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)   # tiny caps -> several buckets
@@ -330,14 +392,19 @@ print("RANK_OK", rank)
 """
 
 
-def test_hipddp_gloo_world2(tmp_path):
-    """bucketed gradient averaging + rank-0 broadcast semantics, 2 processes on CPU (gloo)."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_hipddp_gloo_world(tmp_path, world):
+    """bucketed gradient averaging + rank-0 broadcast semantics on CPU (gloo) at the world sizes the metric names
+    (2, 4, 8 processes; models/model_wrappers.py:964-983): deferred communicator (defer_comm / attach), identical
+    ready_order() on every rank, averaged gradients = mean of the per-rank ones, unused-parameter zero fill, no_sync(),
+    a raising backward, a module applied twice, and bench.py's replica check with one deliberately diverged rank."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29541 + world), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1" if world > 2 else "2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]
 
@@ -458,7 +525,7 @@ def test_bench_supervisor_walks_the_ladder_with_fake_workers(monkeypatch, capsys
     args = b.parse()
     calls = []
 
-    def fake(cmd, env, limit, errp):
+    def fake(cmd, env, limit, errp, abort=None):
         calls.append((cmd, env["MASTER_PORT"], env["HIPSEG_BENCH_WORKER"], limit))
         open(errp, "w").write("boom on rank 1\n")
         loop = cmd[cmd.index("--loop") + 1]
@@ -468,7 +535,20 @@ def test_bench_supervisor_walks_the_ladder_with_fake_workers(monkeypatch, capsys
             return 4, "", False           # replicas out of sync
         return 0, "RCCL banner\n" + json.dumps({"metric": "m", "value": 1.0}) + "\n", False
 
-    assert b.supervise(args, 2, start=fake) == 0
+    class Solo:  # (this test drives ONE supervisor: the agreement between supervisors has its own test below)
+        def port(self, attempt):
+            return None
+
+        def report(self, attempt, rc):
+            pass
+
+        def peer_failed(self, attempt):
+            return False
+
+        def outcome(self, attempt, timeout):
+            return None
+
+    assert b.supervise(args, 2, start=fake, agreement=Solo()) == 0
     doc = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert [f["loop"] for f in doc["fallback_from"]] == ["evgraph", "eager"]
     assert "timed out" in doc["fallback_from"][0]["why"] and "exit code 4" in doc["fallback_from"][1]["why"]
@@ -478,11 +558,72 @@ def test_bench_supervisor_walks_the_ladder_with_fake_workers(monkeypatch, capsys
     assert all(c[0].count("--loop") == 1 and "auto" not in c[0] for c in calls)     # the requested loop was replaced
     assert len({c[1] for c in calls}) == 3 and all(c[2] == "1" for c in calls)      # a fresh port per attempt
     # all loops failing -> non-zero, nothing on stdout; a configuration error (exit 2) ends the ladder at once
-    assert b.supervise(args, 2, start=lambda *a: (open(a[3], "w").close(), (1, "", False))[1]) == 1
+    assert b.supervise(args, 2, start=lambda *a: (open(a[3], "w").close(), (1, "", False))[1], agreement=Solo()) == 1
     assert capsys.readouterr().out.strip() == ""
     n = []
-    assert b.supervise(args, 2, start=lambda *a: (n.append(1), open(a[3], "w").close(), (2, "", False))[2]) == 2
+    assert b.supervise(args, 2, start=lambda *a: (n.append(1), open(a[3], "w").close(), (2, "", False))[2],
+                       agreement=Solo()) == 2
     assert len(n) == 1
+
+
+def test_bench_supervisors_stay_on_the_same_attempt(monkeypatch, tmp_path):
+    """the per-rank supervisors share nothing but the file system.  Rank 1's worker dies EARLY in the
+    first loop while rank 0's would sit in a collective: rank 0's supervisor must stop its worker at once (not after the
+    process-group timeout), and BOTH must start the next loop together, on the SAME freshly probed port -- never one
+    attempt apart.  Two supervisors as threads, fake workers, the real Agreement directory."""
+    import json
+    import threading
+
+    b = _bench()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--loop", "auto"])
+    args = b.parse()
+    log, lock = [], threading.Lock()
+
+    def make_fake(rank):
+        def fake(cmd, env, limit, errp, abort=None):
+            loop = cmd[cmd.index("--loop") + 1]
+            open(errp, "w").write(f"rank {rank} loop {loop}\n")
+            with lock:
+                log.append((rank, loop, int(env["MASTER_PORT"]), int(env["HIPSEG_BENCH_ATTEMPT"]), time.time()))
+            if loop == "evgraph":
+                if rank == 1:
+                    time.sleep(0.3)
+                    return 3, "", False                       # capture failed on this rank only
+                t0 = time.time()                              # rank 0: would hang in its next collective
+                while time.time() - t0 < 60:
+                    if abort is not None and abort():
+                        return -15, "", False
+                    time.sleep(0.05)
+                return -9, "", True
+            return 0, (json.dumps({"metric": "m", "value": 2.0}) + "\n") if rank == 0 else "", False
+        return fake
+
+    rcs, outs = {}, {}
+
+    def sup(rank):
+        ag = b.Agreement(2, rank, directory=str(tmp_path / "rdzv"))
+        import contextlib
+        import io
+
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf) if rank == 0 else contextlib.nullcontext():
+            rcs[rank] = b.supervise(args, 2, start=make_fake(rank), agreement=ag, rank=rank)
+        outs[rank] = buf.getvalue()
+
+    t0 = time.time()
+    ths = [threading.Thread(target=sup, args=(r,)) for r in (0, 1)]
+    [t.start() for t in ths]
+    [t.join(120) for t in ths]
+    assert rcs == {0: 0, 1: 0} and time.time() - t0 < 30      # rank 0 did not wait out its 60-s "collective"
+    by = {(r, a): (loop, port) for r, loop, port, a, _ in log}
+    assert by[(0, 0)][0] == by[(1, 0)][0] == "evgraph" and by[(0, 1)][0] == by[(1, 1)][0] == "eager"
+    assert by[(0, 0)][1] == by[(1, 0)][1] and by[(0, 1)][1] == by[(1, 1)][1] and by[(0, 0)][1] != by[(0, 1)][1]
+    assert len(log) == 4                                        # two attempts per rank, nobody ran a third
+    doc = json.loads(outs[0].strip().splitlines()[-1])
+    assert doc["value"] == 2.0 and [f["loop"] for f in doc["fallback_from"]] == ["evgraph"]
+    assert "peer" in doc["fallback_from"][0]["why"]
 
 
 def test_bench_run_child_kills_the_whole_process_group(tmp_path):

@@ -27,3 +27,5 @@ def test_hipddp_nccl_one_rank(case):
     r = subprocess.run([sys.executable, os.path.join(HERE, "ddp_gpu_worker.py"), case], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and f"CASE_OK {case}" in r.stdout, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
+    if "CAPTURE_RETRIED" in r.stdout:  # (only the in-graph RCCL capture can print it; the event-graph case asserts 1)
+        pytest.xfail("a hipGraph capture with a live process group had to be retried: " + r.stderr[-1500:])
