@@ -46,17 +46,17 @@ extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stre
 // backward through [pool](relu(bn(raw))): [dbeta | dgamma] -> sums, conv-bias gradient -> dbias, d(raw) -> draw.
 // reduced_rows > 0: a->partial already holds that many [2][C] rows of the reduction (written by the data-gradient
 // kernel that produced dy), the reduce launch is skipped.
-static int bn_relu_bwd(const hipseg_convblock_t* a, const void* dy, const void* raw, const float* bn, int pool, float* sums,
-                       float* dbias, void* draw, hipseg_stream_t s, int reduced_rows = 0) {
+static int bn_relu_bwd(const hipseg_convblock_t* a, const void* dy, const void* dy2, const void* raw, const float* bn, int pool,
+                       float* sums, float* dbias, void* draw, hipseg_stream_t s, int reduced_rows = 0) {
     const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
     const int nblk = reduced_rows ? reduced_rows : hipseg_bn_bwd_blocks(B, H, W, C, dt, pool);
     if (!reduced_rows)
-        if (int rc = hipseg_bn_bwd_reduce(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), a->partial,
-                                          B, H, W, C, pool, s))
+        if (int rc = hipseg_bn_bwd_reduce2(dt, dy, dy2, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3),
+                                           a->partial, B, H, W, C, pool, s))
             return rc;
     if (int rc = hipseg_colsum_finalize(a->partial, nblk, 2, C, sums, a->train ? dbias : nullptr, s)) return rc;
-    if (int rc = hipseg_bn_bwd_apply(dt, dy, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), sums,
-                                     (double)B * H * W, a->train ? 0 : 1, draw, nullptr, B, H, W, C, pool, s))
+    if (int rc = hipseg_bn_bwd_apply2(dt, dy, dy2, raw, bnv(bn, C, 0), bnv(bn, C, 1), bnv(bn, C, 2), bnv(bn, C, 3), sums,
+                                      (double)B * H * W, a->train ? 0 : 1, draw, nullptr, B, H, W, C, pool, s))
         return rc;
     if (!a->train) return hipseg_colsum(dt, draw, (long)B * H * W, C, a->colpart, dbias, s);
     return HIPSEG_OK;
@@ -73,7 +73,7 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
     // until d(raw1) exists, i.e. two distinct buffers
     const bool pair = a->draw1 != a->draw2 && hipseg_conv_wgrad_pair_applies(dt, a->C0, a->C1, C, C, B, H, W);
     // second conv layer
-    if (int rc = bn_relu_bwd(a, a->dout, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
+    if (int rc = bn_relu_bwd(a, a->dout, a->dout2, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
     if (!pair)
         if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s))
             return rc;
@@ -92,7 +92,7 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
                                           nullptr, B, H, W, s))
         return rc;
     // first conv layer
-    if (int rc = bn_relu_bwd(a, a->da1, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s, fused_rows)) return rc;
+    if (int rc = bn_relu_bwd(a, a->da1, nullptr, a->raw1, a->bn1, 0, a->sums1, a->db1, a->draw1, s, fused_rows)) return rc;
     if (pair) {
         if (int rc = hipseg_conv_wgrad_pair(dt, a->x0, a->C0, a->x1, a->C1, a->draw1, a->dw1, a->a1, C, a->draw2, a->dw2, C,
                                             a->slabs, B, H, W, s))

@@ -204,16 +204,22 @@ inline int vec_for(int C, int dtype) {
 // One output pixel's worth of backward state.  issue() only issues the global loads (so several
 // pixels can be in flight per lane before the first use), finish() routes dy through maxpool + relu.
 // Shared by reduce and apply so both make identical decisions.
-template <typename T, int V, bool POOL>
+// TWO: the gradient arrives as two tensors (the block's output has two consumers -- an encoder block's pooled output
+// feeds the next block AND a decoder's skip input, /root/reference/models/UNet.py:64-72 -- and each consumer's gradient
+// is handed over on its own instead of being summed by a separate elementwise pass): dy := round_T(dy + dy2), the value
+// that pass would have written.
+template <typename T, int V, bool POOL, bool TWO = false>
 struct PixelCtx {
     static constexpr int NP = POOL ? 4 : 1;
     float xh[NP][V];  // xhat, after finish()
     float g[NP][V];   // routed gradient, after finish()
     float xr[NP][V];  // raw x
     float gv[V];      // raw dy
+    float gv2[TWO ? V : 1];
     long ip[NP];
-    __device__ __forceinline__ void issue(const T* x, const T* dy, long op, int cg, int H, int W, int C) {
+    __device__ __forceinline__ void issue(const T* x, const T* dy, const T* dy2, long op, int cg, int H, int W, int C) {
         ldv<T, V>(dy + op * C + cg * V, gv);
+        if constexpr (TWO) ldv<T, V>(dy2 + op * C + cg * V, gv2);
         if (!POOL) {
             ip[0] = op;
             ldv<T, V>(x + op * C + cg * V, xr[0]);
@@ -231,6 +237,10 @@ struct PixelCtx {
     }
     __device__ __forceinline__ void finish(const float (&mean)[V], const float (&invstd)[V], const float (&sc)[V],
                                            const float (&sh)[V]) {
+        if constexpr (TWO) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) gv[e] = to_f32(from_f32<T>(gv[e] + gv2[e]));
+        }
         if (!POOL) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -259,8 +269,9 @@ struct PixelCtx {
     }
 };
 
-template <typename T, int V, bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int V, bool POOL, bool TWO>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                             const T* __restrict__ x,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ scale,
@@ -284,10 +295,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         if (end > npix_out) end = npix_out;
         constexpr int UNR = POOL ? 2 : BN_UNR;  // pixels in flight per lane
         for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
-            PixelCtx<T, V, POOL> ctx[UNR];
+            PixelCtx<T, V, POOL, TWO> ctx[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, op0 + (long)u * PL, cg, H, W, C);
+                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, dy2, op0 + (long)u * PL, cg, H, W, C);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
                 if (op0 + (long)u * PL < end) {
@@ -324,8 +335,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int V, bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int V, bool POOL, bool TWO>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                            const T* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale,
@@ -357,10 +369,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if (end > npix_out) end = npix_out;
         constexpr int UNR = POOL ? 2 : BN_UNR;  // pixels in flight per lane
         for (long op0 = start + pl; op0 < end; op0 += (long)PL * UNR) {
-            PixelCtx<T, V, POOL> ctx[UNR];
+            PixelCtx<T, V, POOL, TWO> ctx[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, op0 + (long)u * PL, cg, H, W, C);
+                if (op0 + (long)u * PL < end) ctx[u].issue(x, dy, dy2, op0 + (long)u * PL, cg, H, W, C);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
                 if (op0 + (long)u * PL < end) {
@@ -582,6 +594,12 @@ static int check_red(const char* name, int C, int V) {
 extern "C" int hipseg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* mean, const float* invstd,
                                     const float* scale, const float* shift, float* partial, int B, int H, int W,
                                     int C, int pool, hipseg_stream_t stream) {
+    return hipseg_bn_bwd_reduce2(dtype, dy, nullptr, x, mean, invstd, scale, shift, partial, B, H, W, C, pool, stream);
+}
+
+extern "C" int hipseg_bn_bwd_reduce2(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                                     const float* invstd, const float* scale, const float* shift, float* partial, int B,
+                                     int H, int W, int C, int pool, hipseg_stream_t stream) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_bwd_reduce: bad dtype");
     HS_REQUIRE(dy && x && mean && invstd && scale && shift && partial && B > 0 && H > 0 && W > 0 && C > 0,
                "bn_bwd_reduce: bad arguments");
@@ -591,14 +609,18 @@ extern "C" int hipseg_bn_bwd_reduce(int dtype, const void* dy, const void* x, co
     const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     const RedGeo g = red_geo(npix, C, V);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define BN_RED_LAUNCH(POOL_, TWO_)                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, V_, POOL_, TWO_>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,     \
+                       (const T_*)dy2, (const T_*)x, mean, invstd, scale, shift, partial, npix, H, W, C, g.CG, g.PL, \
+                       g.ppb)
     DISPATCH_TV(dtype, V, {
-        if (pool)
-            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, V_, true>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
-                               (const T_*)x, mean, invstd, scale, shift, partial, npix, H, W, C, g.CG, g.PL, g.ppb);
-        else
-            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, V_, false>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
-                               (const T_*)x, mean, invstd, scale, shift, partial, npix, H, W, C, g.CG, g.PL, g.ppb);
+        if (pool) {
+            if (dy2) BN_RED_LAUNCH(true, true); else BN_RED_LAUNCH(true, false);
+        } else {
+            if (dy2) BN_RED_LAUNCH(false, true); else BN_RED_LAUNCH(false, false);
+        }
     });
+#undef BN_RED_LAUNCH
     HS_LAUNCH_CHECK("bn_bwd_reduce");
     return HIPSEG_OK;
 }
@@ -607,6 +629,14 @@ extern "C" int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, con
                                    const float* scale, const float* shift, const float* sums, double count, int eval,
                                    void* dx, float* dbias, int B, int H, int W, int C, int pool,
                                    hipseg_stream_t stream) {
+    return hipseg_bn_bwd_apply2(dtype, dy, nullptr, x, mean, invstd, scale, shift, sums, count, eval, dx, dbias, B, H, W, C,
+                                pool, stream);
+}
+
+extern "C" int hipseg_bn_bwd_apply2(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                                    const float* invstd, const float* scale, const float* shift, const float* sums,
+                                    double count, int eval, void* dx, float* dbias, int B, int H, int W, int C, int pool,
+                                    hipseg_stream_t stream) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "bn_bwd_apply: bad dtype");
     HS_REQUIRE(dy && x && mean && invstd && scale && shift && dx && (eval || sums) && count > 0 && C > 0,
                "bn_bwd_apply: bad arguments");
@@ -617,16 +647,18 @@ extern "C" int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, con
     const RedGeo g = red_geo(npix, C, V);
     const float inv = (float)(1.0 / count);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define BN_APP_LAUNCH(POOL_, TWO_)                                                                                 \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, V_, POOL_, TWO_>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,     \
+                       (const T_*)dy2, (const T_*)x, mean, invstd, scale, shift, sums, inv, eval, (T_*)dx, dbias,    \
+                       npix, H, W, C, g.CG, g.PL, g.ppb)
     DISPATCH_TV(dtype, V, {
-        if (pool)
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, V_, true>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
-                               (const T_*)x, mean, invstd, scale, shift, sums, inv, eval, (T_*)dx, dbias, npix, H, W,
-                               C, g.CG, g.PL, g.ppb);
-        else
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T_, V_, false>), dim3(g.nblk), dim3(256), 0, s, (const T_*)dy,
-                               (const T_*)x, mean, invstd, scale, shift, sums, inv, eval, (T_*)dx, dbias, npix, H, W,
-                               C, g.CG, g.PL, g.ppb);
+        if (pool) {
+            if (dy2) BN_APP_LAUNCH(true, true); else BN_APP_LAUNCH(true, false);
+        } else {
+            if (dy2) BN_APP_LAUNCH(false, true); else BN_APP_LAUNCH(false, false);
+        }
     });
+#undef BN_APP_LAUNCH
     HS_LAUNCH_CHECK("bn_bwd_apply");
     return HIPSEG_OK;
 }

@@ -131,39 +131,61 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix) end = npix;
+        // Every load of an iteration is issued UNCONDITIONALLY (tail pixels re-read the block's last pixel and are
+        // selected to 0) before the first use: inside `if (p < end)` regions the compiler kept one pixel in flight per
+        // lane (load, wait, add, next pixel) and the kernel ran at 2.4 TB/s of its 147 MB (round 3: 60 us).
         constexpr int UNR = 4;  // pixels in flight per lane
+        const unsigned hw_n = (unsigned)HW;  // 32-bit divides (launch condition: B*HW < 2^31)
         for (long p0 = start + pl; p0 < end; p0 += (long)PL * UNR) {
-            float g[UNR][V], xv[UNR][MAXCIN];
+            typename VecOf<T>::type gr[UNR], gr2[UNR];
+            float xv[UNR][MAXCIN];
+            bool ok[UNR];
+            long pc[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const long p = p0 + (long)u * PL;
-                if (p < end) {
-                    const unsigned pu = (unsigned)p, hw_n = (unsigned)HW;  // 32-bit divide (launch condition)
-                    const unsigned n = pu / hw_n, hw = pu - n * hw_n;
-                    ldv<T, V>(dy + p * Cout + cg * V, g[u]);
-                    if (dy2) {  // second gradient of the same tensor (the stem output also feeds the last decoder block)
-                        float g2[V];
-                        ldv<T, V>(dy2 + p * Cout + cg * V, g2);
+                ok[u] = p < end;
+                pc[u] = ok[u] ? p : end - 1;
+            }
+            if constexpr (V > 1) {
 #pragma unroll
-                        for (int e = 0; e < V; ++e) g[u][e] += g2[e];
-                    }
+                for (int u = 0; u < UNR; ++u) gr[u] = *reinterpret_cast<const typename VecOf<T>::type*>(dy + pc[u] * Cout + cg * V);
+                if (dy2) {  // (uniform) second gradient of the same tensor (the stem output also feeds the last decoder block)
 #pragma unroll
-                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = ci < Cin ? x[((size_t)n * Cin + ci) * hw_n + hw] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) g[u][e] = 0.f;
-#pragma unroll
-                    for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = 0.f;
+                    for (int u = 0; u < UNR; ++u)
+                        gr2[u] = *reinterpret_cast<const typename VecOf<T>::type*>(dy2 + pc[u] * Cout + cg * V);
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
+                const unsigned pu = (unsigned)pc[u], n = pu / hw_n, hw = pu - n * hw_n;
+#pragma unroll
+                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = x[((size_t)n * Cin + (ci < Cin ? ci : Cin - 1)) * hw_n + hw];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                float g[V];
+                if constexpr (V > 1) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g[e] = (float)gr[u][e];
+                    if (dy2) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) g[e] += (float)gr2[u][e];
+                    }
+                } else {
+                    g[0] = (float)dy[pc[u] * Cout + cg];
+                    if (dy2) g[0] += (float)dy2[pc[u] * Cout + cg];
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] = ok[u] ? g[e] : 0.f;
 #pragma unroll
                 for (int ci = 0; ci < MAXCIN; ++ci)
+                    if (ci < Cin) {
 #pragma unroll
-                    for (int e = 0; e < V; ++e) acc[ci][e] = fmaf(g[u][e], xv[u][ci], acc[ci][e]);
+                        for (int e = 0; e < V; ++e) acc[ci][e] = fmaf(g[e], xv[u][ci], acc[ci][e]);
+                    }
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[MAXCIN][e] += g[u][e];
+                for (int e = 0; e < V; ++e) acc[MAXCIN][e] += g[e];
             }
         }
     }

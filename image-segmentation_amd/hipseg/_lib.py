@@ -58,6 +58,8 @@ PROTOTYPES = {
     "hipseg_bn_bwd_blocks": (I, [I, I, I, I, I, I]),
     "hipseg_bn_bwd_reduce": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_bn_bwd_apply": (I, [I, P, P, P, P, P, P, P, c_double, I, P, P, I, I, I, I, I, P]),
+    "hipseg_bn_bwd_reduce2": (I, [I, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_bn_bwd_apply2": (I, [I, P, P, P, P, P, P, P, P, c_double, I, P, P, I, I, I, I, I, P]),
     "hipseg_colsum_finalize": (I, [P, I, I, I, P, P, P]),
     "hipseg_colsum_blocks": (I, [L, I, I]),
     "hipseg_colsum": (I, [I, P, L, I, P, P, P]),
@@ -97,7 +99,7 @@ class ConvBlockArgs(ctypes.Structure):
                 + [("eps", c_float), ("momentum", c_float)]
                 + [(n, c_void_p) for n in ("x0", "x1", "wp1", "wp2", "wp1t", "wp2t", "b1", "g1", "be1", "b2", "g2", "be2",
                                             "rm1", "rv1", "rm2", "rv2", "nbt1", "nbt2", "raw1", "a1", "raw2", "out", "bn1",
-                                            "bn2", "stats", "dout", "draw2", "da1", "draw1", "dx0", "dx1", "dw1", "dw2",
+                                            "bn2", "stats", "dout", "dout2", "draw2", "da1", "draw1", "dx0", "dx1", "dw1", "dw2",
                                             "db1", "db2", "sums1", "sums2", "partial", "slabs", "colpart")])
 
 # functions whose int return value is a geometry answer, not a status code

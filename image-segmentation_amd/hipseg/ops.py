@@ -390,7 +390,7 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     return raw, act, bn, wpt
 
 
-def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None):
+def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None, dy2=None):
     """backward through [pool](relu(bn(raw))): returns (d_raw, dgamma, dbeta, dbias_conv); `bias`, `gamma`, `beta` are
     the conv-bias / BN parameters (for their gradient destinations).  `reduced` = (partial, rows): the reduction's
     partial rows already exist (written by the data-gradient kernel that produced dy, hipseg_conv3_dgrad_bnstats)."""
@@ -403,16 +403,18 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None):
     else:
         nblk = L.bn_bwd_blocks(B, H, W, C, dt, int(pool))
         partial = _f32(nblk * 2 * C, dev)
-        _hbm("bn_bwd_reduce" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * (1.25 if pool else 2.0),
-             L.bn_bwd_reduce, dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
+        n2 = (0.25 if pool else 1.0) if dy2 is not None else 0.0  # (a second gradient tensor of dy's size)
+        _hbm("bn_bwd_reduce" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * ((1.25 if pool else 2.0) + n2),
+             L.bn_bwd_reduce2, dt, ptr(dy), ptr(dy2), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(partial),
              B, H, W, C, int(pool), s)
     # conv bias in front of train-mode BN: d(bias) = sum_pixels d_raw == 0 exactly (sum(g - mean g) = 0 and
     # sum(xhat) = 0); the reference's autograd returns only rounding noise here (~1e-8).  The finalize launch writes it.
     dbias = grad_out(bias)
     L.colsum_finalize(ptr(partial), nblk, 2, C, ptr(sums), ptr(dbias) if train else 0, s)
     draw = nhwc_empty(B, C, H, W, raw.dtype, dev)
-    _hbm("bn_bwd_apply" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * (2.25 if pool else 3.0),
-         L.bn_bwd_apply, dt, ptr(dy), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
+    n2 = (0.25 if pool else 1.0) if dy2 is not None else 0.0
+    _hbm("bn_bwd_apply" + ("+pool" if pool else ""), B * H * W * C * _esz(dt) * ((2.25 if pool else 3.0) + n2),
+         L.bn_bwd_apply2, dt, ptr(dy), ptr(dy2), ptr(raw), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(sums),
          float(B * H * W), 0 if train else 1, ptr(draw), 0, B, H, W, C, int(pool), s)
     if not train:
         npix = B * H * W
@@ -457,7 +459,7 @@ def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, 
     return out
 
 
-def _block_backward(ctx, dout):
+def _block_backward(ctx, dout, dout2=None):
     """the matching backward through hipseg_convblock_backward (BN backward x2, weight gradients x2, data gradients)."""
     import ctypes
 
@@ -466,6 +468,7 @@ def _block_backward(ctx, dout):
     B, C, H, W = raw2.shape
     dev, td = raw2.device, raw2.dtype
     dout = as_nhwc(dout, td)
+    dout2 = as_nhwc(dout2, td) if dout2 is not None else None
     b1, g1, be1, b2, g2, be2 = ctx.small
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
@@ -488,22 +491,36 @@ def _block_backward(ctx, dout):
     slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, c0 + c1, C, B, H, W), L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W)), dev)
     colpart = None if train else _f32(L.colsum_blocks(B * H * W, C, dt) * C, dev)
     A.dout, A.draw2, A.da1, A.draw1, A.dx0, A.dx1 = ptr(dout), ptr(draw), ptr(da1), ptr(draw1), ptr(dx0), ptr(dx1)
+    A.dout2 = ptr(dout2)
     A.dw1, A.dw2, A.db1, A.db2, A.sums1, A.sums2 = ptr(dw1), ptr(dw2), ptr(db1), ptr(db2), ptr(sums1), ptr(sums2)
     A.partial, A.slabs, A.colpart = ptr(partial), ptr(slabs), ptr(colpart)
     A.wp1t, A.wp2t, A.need_dx = ptr(wp1t), ptr(wp2t), int(dx0 is not None)
     L.convblock_backward(ctypes.addressof(A), _stream())
     return (dx0, dx1, dw1, db1, sums1[C:], sums1[:C], dw2, db2, sums2[C:], sums2[:C], None, None, None, None, None, None,
-            None, None, None)
+            None, None, None, None)
 
 
 class ConvBlockFn(torch.autograd.Function):
     """[cat(x0,x1)] -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU [-> MaxPool2d(2,2)]
     = ConvBlock / ConvBlockDownsample / the conv half of ConvBlockUpsampleSkip
-    (models/processing_blocks.py:40-52, 69-77, 108-109)."""
+    (models/processing_blocks.py:40-52, 69-77, 108-109).
+    `two`: return the output TWICE (the second an alias of the first), one per consumer -- an encoder block's pooled
+    output feeds the next block and a decoder block's skip input (models/UNet.py:64-72).  Given one tensor object,
+    autograd sums the two gradients in an elementwise pass of its own before this backward runs; with one alias per
+    consumer each gradient arrives on its own and the BatchNorm-backward kernels read both (hipseg_bn_bwd_*2)."""
 
     @staticmethod
     def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool,
-                no_grad=False):
+                no_grad=False, two=False):
+        out = ConvBlockFn._forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train,
+                                   pool, no_grad)
+        if two:
+            ctx.set_materialize_grads(False)  # an unused alias hands None to backward, not a tensor of zeros
+            return out, out.detach()
+        return out
+
+    @staticmethod
+    def _forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, no_grad):
         dt = _dt(x0)
         # (grad mode is off inside Function.forward, and needs_input_grad stays True for parameters under
         # torch.no_grad(): the caller passes whether a graph is being recorded at all)
@@ -523,15 +540,20 @@ class ConvBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return (None,) * 20
         if ctx.blk is not None:
-            return _block_backward(ctx, dout)
+            return _block_backward(ctx, dout, dout2)
         x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors
         dt, train, pool = ctx.dt, ctx.train, ctx.pool
         B, C, H, W = raw2.shape
         dev = raw2.device
         s = _stream()
         dout = as_nhwc(dout, raw2.dtype)
+        dout2 = as_nhwc(dout2, raw2.dtype) if dout2 is not None else None
         b1, g1, be1, b2, g2, be2 = ctx.small
         c0 = x0.shape[1]
         c1 = x1.shape[1] if x1 is not None else 0
@@ -539,7 +561,7 @@ class ConvBlockFn(torch.autograd.Function):
         # and the first layer's BatchNorm-backward sums out of the data-gradient epilogue, where the shapes allow
         pair = bool(L.conv_wgrad_pair_applies(dt, c0, c1, C, C, B, H, W))
         # ---- second conv layer
-        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2)
+        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2, dy2=dout2)
         dw2 = grad_out(w2)
         if not pair:
             _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
@@ -575,7 +597,8 @@ class ConvBlockFn(torch.autograd.Function):
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
             dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
             igemm(dt, L.CONV3, draw1, C, None, 0, wp1t, None, dx0, c0, dx1, c1, None, B, H, W)
-        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None, None)
+        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None, None,
+                None)
 
 
 class ConvT2x2Fn(torch.autograd.Function):

@@ -8,6 +8,7 @@ from models.processing_blocks import ConvBlock, ConvBlockDownsample, ConvBlockUp
 
 
 _NO_STEM_ALIAS = bool(__import__("os").environ.get("HIPSEG_NO_STEM_ALIAS"))
+_NO_ENC_ALIAS = bool(__import__("os").environ.get("HIPSEG_NO_ENC_ALIAS"))  # A/B switch: autograd sums the skip gradients
 
 
 def _stem(conv, x, two=False):
@@ -51,8 +52,13 @@ class _UNetBase(nn.Module):
         h, h_skip = _stem(self.input, x, two=True)  # one alias per consumer: enc1 below, the last decoder block's skip
         skips = [h_skip]
         for k in range(1, len(self._enc) + 1):
-            h = getattr(self, f"enc{k}")(h)
-            skips.append(h)
+            # one alias per consumer (next block / the decoder's skip input): no gradient-summing pass in backward
+            enc = getattr(self, f"enc{k}")
+            if _NO_ENC_ALIAS or not torch.is_grad_enabled():
+                h = h_skip = enc(h)
+            else:
+                h, h_skip = enc.forward_two(h)
+            skips.append(h_skip)
         h = self.bottleneck(h) if fuse is None else fuse(h, skips)
         for k in range(1, len(self._dec) + 1):
             h = getattr(self, f"dec{k}")(h, skips[-k])

@@ -17,8 +17,9 @@ from hipseg import ops
 
 
 
-def _double_conv(seq, x, skip, pool):
-    """seq = (conv, bn, relu, conv, bn, relu) parameter container of one ConvBlock."""
+def _double_conv(seq, x, skip, pool, two=False):
+    """seq = (conv, bn, relu, conv, bn, relu) parameter container of one ConvBlock.
+    two: (output, alias of the output) for a block whose output has two consumers (see ops.ConvBlockFn)."""
     c1, n1, _, c2, n2, _ = seq
     td = ops._tdtype(ops.precision())
     x = ops.as_nhwc(x, td)
@@ -33,7 +34,7 @@ def _double_conv(seq, x, skip, pool):
     stats = (n1.running_mean, n1.running_var, n1.num_batches_tracked, n2.running_mean, n2.running_var,
              n2.num_batches_tracked)
     return ops.ConvBlockFn.apply(x, skip, c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight,
-                                 n2.bias, *stats, train, pool, not torch.is_grad_enabled())
+                                 n2.bias, *stats, train, pool, not torch.is_grad_enabled(), two)
 
 
 def _conv_seq(cin, cout, k, pad):
@@ -66,6 +67,13 @@ class ConvBlockDownsample(nn.Module):
     @torch.compiler.disable
     def forward(self, x):
         return _double_conv(self.block[0].conv, x, None, True)
+
+    @torch.compiler.disable
+    def forward_two(self, x):
+        """(pooled output, alias of it): for callers that feed the output to TWO consumers (the U-Nets: next encoder
+        block + a decoder's skip input) -- each consumer's gradient then reaches the block's backward on its own
+        instead of through an elementwise sum by autograd (see ops.ConvBlockFn)."""
+        return _double_conv(self.block[0].conv, x, None, True, two=True)
 
 
 def _upsample(up, x):

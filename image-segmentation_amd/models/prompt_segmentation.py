@@ -70,9 +70,11 @@ class ClipUnetPrompt(nn.Module):
         clip_features = self.clip_feature_extractor(X)
         ops.prepack(self, ops.precision())  # all 3x3 conv / ConvT operands of this step, one launch
         inp, inp_skip = _stem(self.input, X, two=True)  # (an alias per consumer, see ops.StemFn)
-        enc1 = self.enc1(inp)
-        enc2 = self.enc2(enc1)
-        enc3 = self.enc3(enc2)
+        # (enc1 / enc2 feed the next block AND a decoder's skip input: one alias per consumer, see ops.ConvBlockFn)
+        grad = torch.is_grad_enabled()
+        e1, enc1 = self.enc1.forward_two(inp) if grad else (self.enc1(inp),) * 2
+        e2, enc2 = self.enc2.forward_two(e1) if grad else (self.enc2(e1),) * 2
+        enc3 = self.enc3(e2)
         prompt_embedding = self.prompt_encoder(prompt_heatmap.float())
         attention_output = ops.as_nhwc(_fuse_clip(self, enc3, clip_features), prompt_embedding.dtype)
         # prompt_fusion(cat([attention_output, prompt_embedding], dim=1)): dual-source 1x1 conv, no concatenation

@@ -207,6 +207,17 @@ int hipseg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* m
                         const float* invstd, const float* scale, const float* shift,
                         const float* sums, double count, int eval, void* dx, float* dbias, int B,
                         int H, int W, int C, int pool, hipseg_stream_t stream);
+/* The same two passes when the gradient arrives as TWO tensors of dy's shape (the normalised tensor has two consumers:
+ * an encoder block's pooled output feeds the next block and a decoder's skip input, models/UNet.py:64-72): every element
+ * is read as round(dy + dy2) in the activation dtype -- the value autograd's own accumulation pass would have written
+ * -- and that pass (read 2, write 1 tensor) does not run.  dy2 == NULL: identical to the one-tensor entry points. */
+int hipseg_bn_bwd_reduce2(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                          const float* invstd, const float* scale, const float* shift, float* partial,
+                          int B, int H, int W, int C, int pool, hipseg_stream_t stream);
+int hipseg_bn_bwd_apply2(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, const float* sums,
+                         double count, int eval, void* dx, float* dbias, int B, int H, int W, int C, int pool,
+                         hipseg_stream_t stream);
 
 /* out[r][c] = sum_blk partial[blk][r][c]  (rows = 1 or 2), fixed order (deterministic).  zero_out != NULL: the same
  * launch also writes zero_out[0..C) = 0 (the conv-bias gradient in front of a train-mode BatchNorm is exactly 0).
@@ -245,7 +256,7 @@ typedef struct hipseg_convblock {
     int64_t *nbt1, *nbt2;
     void *raw1, *a1, *raw2, *out;
     float *bn1, *bn2, *stats;
-    const void* dout;
+    const void *dout, *dout2; /* dout2: optional second gradient of `out` (two consumers), see hipseg_bn_bwd_apply2 */
     void *draw2, *da1, *draw1, *dx0, *dx1;
     float *dw1, *dw2, *db1, *db2, *sums1, *sums2, *partial, *slabs, *colpart;
 } hipseg_convblock_t;
