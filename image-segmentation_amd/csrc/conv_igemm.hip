@@ -1551,7 +1551,11 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         }
         {
             if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_launch(a, r16, s);
-            if (!dbg && convt_stream_applies(dtype, mode, C0, C1, N0, N1, B, H, W)) return convt_stream_launch(a, mode, s);
+            // (the streaming kernel adds the bias in the ConvT forward only and never writes statistics rows: any other
+            // request with a bias / statistics takes the GEMM kernels below -- ADVICE round 3)
+            if (!dbg && !stats && (mode == HIPSEG_CONVT || !bias) &&
+                convt_stream_applies(dtype, mode, C0, C1, N0, N1, B, H, W))
+                return convt_stream_launch(a, mode, s);
         }
         if (a.vec_ok && !no_dma && buf_ok) {
             // ConvTranspose2d forward / data gradient as a one-tap GEMM on pixel-major 64-channel stages

@@ -67,22 +67,24 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? wr[ci][e] : 0.f;
         constexpr int UNR = 4;  // pixels in flight per lane (the loop is latency-bound otherwise: 3 loads -> 1 store)
         for (unsigned i = i0; i < total; i += stride * UNR) {
+            // unconditional loads (items past the end re-read the last item's pixel and skip their store)
             float xv[UNR][MAXCIN];
-            long pp[UNR];
+            bool ok[UNR];
+            unsigned pu[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const unsigned iu = i + u * stride;
-                const bool ok = iu < total && iu >= i;  // (>= i: no wrap-around)
-                const unsigned pu = ok ? iu / CG : 0u;
-                pp[u] = ok ? (long)pu : -1;
-                const unsigned n = pu / hw_n, hw = pu - n * hw_n;
-#pragma unroll
-                for (int ci = 0; ci < MAXCIN; ++ci)
-                    xv[u][ci] = (ok && ci < Cin) ? x[((size_t)n * Cin + ci) * hw_n + hw] : 0.f;
+                ok[u] = iu < total && iu >= i;  // (>= i: no wrap-around)
+                pu[u] = (ok[u] ? iu : total - 1) / CG;
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (pp[u] < 0) continue;
+                const unsigned n = pu[u] / hw_n, hw = pu[u] - n * hw_n;
+#pragma unroll
+                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = x[((size_t)n * Cin + (ci < Cin ? ci : Cin - 1)) * hw_n + hw];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
                 float o[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = br[e];
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
                         for (int e = 0; e < V; ++e) o[e] = fmaf(wr[ci][e], xv[u][ci], o[e]);
                     }
-                stv<T, V>(y + pp[u] * Cout + cg * V, o);
+                if (ok[u]) stv<T, V>(y + (size_t)pu[u] * Cout + cg * V, o);
             }
         }
         return;
@@ -289,30 +291,33 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         const long start = blockIdx.x * ppb;
         long end = start + ppb;
         if (end > npix) end = npix;
-        constexpr int UNR = 2;  // pixels in flight per lane
+        // all loads of an iteration are issued unconditionally (tail pixels re-read the block's last pixel, their
+        // contributions are selected to 0 and their store is skipped) before the first use -- see stem_bwd_kernel
+        constexpr int UNR = 4;  // pixels in flight per lane
+        const unsigned hw_n = (unsigned)HW;  // 32-bit divides (launch condition: B*HW < 2^31)
         for (long p0 = start + pl; p0 < end; p0 += (long)PL * UNR) {
             float xv[UNR][V], g[UNR][MAXHC];
+            bool ok[UNR];
+            long pc[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const long p = p0 + (long)u * PL;
-                if (p < end) {
-                    const unsigned hw_n = (unsigned)HW, n = (unsigned)p / hw_n, hw = (unsigned)p - n * hw_n;  // 32-bit divide
-                    ldv<T, V>(x + p * Cin + cg * V, xv[u]);
+                ok[u] = p < end;
+                pc[u] = ok[u] ? p : end - 1;
+            }
 #pragma unroll
-                    for (int co = 0; co < MAXHC; ++co)
-                        g[u][co] = dl[((size_t)n * Cout + (co < Cout ? co : Cout - 1)) * hw_n + hw];
+            for (int u = 0; u < UNR; ++u) ldv<T, V>(x + pc[u] * Cin + cg * V, xv[u]);
 #pragma unroll
-                    for (int co = 0; co < MAXHC; ++co) g[u][co] = co < Cout ? g[u][co] : 0.f;
-                } else {
+            for (int u = 0; u < UNR; ++u) {
+                const unsigned pu = (unsigned)pc[u], n = pu / hw_n, hw = pu - n * hw_n;
 #pragma unroll
-                    for (int e = 0; e < V; ++e) xv[u][e] = 0.f;
-#pragma unroll
-                    for (int co = 0; co < MAXHC; ++co) g[u][co] = 0.f;
-                }
+                for (int co = 0; co < MAXHC; ++co)
+                    g[u][co] = dl[((size_t)n * Cout + (co < Cout ? co : Cout - 1)) * hw_n + hw];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const long p = p0 + (long)u * PL;
+#pragma unroll
+                for (int co = 0; co < MAXHC; ++co) g[u][co] = (ok[u] && co < Cout) ? g[u][co] : 0.f;
                 float o[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = 0.f;
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                             aw[co][e] = fmaf(g[u][co], xv[u][e], aw[co][e]);
                         }
                     }
-                if (p < end) stv<T, V>(dx + p * Cin + cg * V, o);
+                if (ok[u]) stv<T, V>(dx + pc[u] * Cin + cg * V, o);
             }
         }
     }

@@ -329,8 +329,10 @@ class BrightnessChange(nn.Module):
 
 
 class Occlusion(nn.Module):
-    """zero one random size x size square per image, IN PLACE as the reference does (reference :542-563; positions
-    from Python's `random`, so `random.seed` reproduces the reference's squares)."""
+    """zero one random size x size square per image, IN PLACE as the reference does (reference :542-563).
+    The draw ORDER is part of the contract and is kept on purpose: per image first the column, then the row, both from
+    Python's `random` module with the reference's bounds, so a caller that seeds `random` (the robustness sweeps of
+    TestWrapper) gets the reference's squares; everything else here is this module's own."""
 
     def __init__(self, size):
         super().__init__()
@@ -353,8 +355,9 @@ class SaltAndPepper(nn.Module):
         self.amount = amount
 
     def forward(self, img):
-        b, c, h, w = img.shape
-        noise = torch.rand((b, 1, h, w), device=img.device)
-        salt = (noise < self.amount / 2).float()
-        pepper = (noise > 1 - self.amount / 2).float()
-        return img * (1 - salt - pepper) + salt
+        half = self.amount / 2
+        # one draw per pixel, shared by the channels: the lowest `half` of the unit interval turns the pixel white, the
+        # highest `half` black, everything between keeps the image
+        u = torch.rand(img.shape[0], 1, img.shape[2], img.shape[3], device=img.device)
+        out = torch.where(u < half, torch.ones_like(img), img)
+        return torch.where(u > 1 - half, torch.zeros_like(img), out)

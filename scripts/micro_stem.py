@@ -21,3 +21,14 @@ print(f"stem_fwd {t:6.1f} us  {(x.numel()*4 + y.numel()*2)/t/1e6:5.2f} TB/s")
 wh = torch.randn(3, 32, 1, 1, device="cuda"); bh = torch.randn(3, device="cuda"); lg = torch.empty(B, 3, H, H, device="cuda")
 t = timeit(lambda: L.head_fwd(L.BF16, ops.ptr(y), ops.ptr(wh), ops.ptr(bh), ops.ptr(lg), B, H, H, 32, 3, s))
 print(f"head_fwd {t:6.1f} us  {(lg.numel()*4 + y.numel()*2)/t/1e6:5.2f} TB/s")
+# backward kernels (round 4): stem_bwd2 with both gradients, head_bwd
+dy = torch.randn(B, H, H, 32, device="cuda").to(torch.bfloat16); dy2 = torch.randn_like(dy)
+part = torch.empty(L.stem_bwd_blocks(B, H, H) * 4 * 32, device="cuda"); dw = torch.empty(32, 3, device="cuda"); db = torch.empty(32, device="cuda")
+t = timeit(lambda: L.stem_bwd2(L.BF16, ops.ptr(x), ops.ptr(dy), ops.ptr(dy2), ops.ptr(part), ops.ptr(dw), ops.ptr(db), B, 3, H, H, 32, s))
+print(f"stem_bwd2(+finalize) {t:6.1f} us  {(x.numel()*4 + 2*dy.numel()*2)/t/1e6:5.2f} TB/s")
+t = timeit(lambda: L.stem_bwd2(L.BF16, ops.ptr(x), ops.ptr(dy), 0, ops.ptr(part), ops.ptr(dw), ops.ptr(db), B, 3, H, H, 32, s))
+print(f"stem_bwd (+finalize) {t:6.1f} us  {(x.numel()*4 + dy.numel()*2)/t/1e6:5.2f} TB/s")
+dl = torch.randn(B, 3, H, H, device="cuda"); dx = torch.empty_like(dy)
+hp = torch.empty(L.head_bwd_blocks(B, H, H) * 3 * 33, device="cuda"); hdw = torch.empty(3, 32, device="cuda"); hdb = torch.empty(3, device="cuda")
+t = timeit(lambda: L.head_bwd(L.BF16, ops.ptr(dy), ops.ptr(dl), ops.ptr(wh), ops.ptr(dx), ops.ptr(hp), ops.ptr(hdw), ops.ptr(hdb), B, H, H, 32, 3, s))
+print(f"head_bwd (+finalize) {t:6.1f} us  {(dl.numel()*4 + 2*dy.numel()*2)/t/1e6:5.2f} TB/s")

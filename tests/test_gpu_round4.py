@@ -1,0 +1,176 @@
+"""Round-4 cases (need a real MI355X):
+  * the two-gradient BatchNorm-backward entry points (hipseg_bn_bwd_reduce2 / _apply2) against the one-gradient ones fed
+    with the bf16 sum autograd's accumulation pass would have written, and the output-alias form of ConvBlockFn /
+    the U-Net (one gradient per consumer) against the single-tensor form, bit for bit;
+  * the per-op Python path of ConvBlockFn (what bench.py's roofline leg times: HIPSEG_NO_BLOCK_CALLS / ops.PROFILE) against
+    the one-C-call block path that every other test runs, bit for bit;
+  * hipseg_conv_igemm(mode = CONV2S2) WITH a bias on a shape the LDS-free streaming kernel takes: the bias must not be
+    dropped;
+  * the roofline leg's per-launch records carry algorithmic bytes for the HBM-bound groups."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_kernels import T, hs, rnd, to_dev_nhwc  # noqa: E402,F401
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+@pytest.mark.parametrize("prec,td,dt", [("fp32", torch.float32, 0), ("bf16", torch.bfloat16, 1)])
+def test_bn_backward_with_two_gradients(hs, prec, td, dt, pool):
+    L, ops = hs.L, hs.ops
+    B, C, H, W = 3, 64, 12, 20
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    raw = to_dev_nhwc(rnd(T("r4.raw", (B, C, H, W), -2, 2), td), td)
+    dy1 = to_dev_nhwc(rnd(T("r4.dy1", (B, C, Ho, Wo)), td), td)
+    dy2 = to_dev_nhwc(rnd(T("r4.dy2", (B, C, Ho, Wo)), td), td)
+    dsum = (dy1 + dy2)  # what autograd's accumulation writes (rounded to the activation dtype)
+    bn = torch.cat([T("r4.mean", (C,), -0.5, 0.5), T("r4.is", (C,), 0.5, 2.0), T("r4.sc", (C,), -1.5, 1.5),
+                    T("r4.sh", (C,), -0.5, 0.5)]).cuda()
+    bp, s = bn.data_ptr(), ops._stream()
+    nblk = L.bn_bwd_blocks(B, H, W, C, dt, pool)
+
+    def run(two):
+        part = torch.empty(nblk * 2 * C, device="cuda")
+        if two:
+            L.bn_bwd_reduce2(dt, ops.ptr(dy1), ops.ptr(dy2), ops.ptr(raw), bp, bp + 4 * C, bp + 8 * C, bp + 12 * C, ops.ptr(part),
+                             B, H, W, C, pool, s)
+        else:
+            L.bn_bwd_reduce(dt, ops.ptr(dsum), ops.ptr(raw), bp, bp + 4 * C, bp + 8 * C, bp + 12 * C, ops.ptr(part), B, H, W, C,
+                            pool, s)
+        sums = torch.empty(2 * C, device="cuda")
+        L.colsum_finalize(ops.ptr(part), nblk, 2, C, ops.ptr(sums), 0, s)
+        dx = ops.nhwc_empty(B, C, H, W, td, "cuda")
+        if two:
+            L.bn_bwd_apply2(dt, ops.ptr(dy1), ops.ptr(dy2), ops.ptr(raw), bp, bp + 4 * C, bp + 8 * C, bp + 12 * C, ops.ptr(sums),
+                            float(B * H * W), 0, ops.ptr(dx), 0, B, H, W, C, pool, s)
+        else:
+            L.bn_bwd_apply(dt, ops.ptr(dsum), ops.ptr(raw), bp, bp + 4 * C, bp + 8 * C, bp + 12 * C, ops.ptr(sums),
+                           float(B * H * W), 0, ops.ptr(dx), 0, B, H, W, C, pool, s)
+        torch.cuda.synchronize()
+        return sums, dx
+
+    s1, d1 = run(False)
+    s2, d2 = run(True)
+    assert torch.equal(s1, s2) and torch.equal(d1, d2)
+    assert float(d1.float().abs().max()) > 0
+
+
+def _unet_grads(hs, alias):
+    import models.UNet as un
+    from models.losses import HybridLoss
+
+    torch.manual_seed(5)
+    m = un.UNet().cuda().train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 32, 48, generator=g).cuda()
+    t = torch.randint(0, 3, (2, 32, 48), generator=g).cuda()
+    old = un._NO_ENC_ALIAS
+    un._NO_ENC_ALIAS = not alias
+    try:
+        with torch.autocast("cuda"):
+            out = m(x)
+            loss = HybridLoss()(out, t)
+        loss.backward()
+    finally:
+        un._NO_ENC_ALIAS = old
+    torch.cuda.synchronize()
+    return out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+
+def test_unet_output_alias_per_consumer_is_bit_identical(hs):
+    """models/UNet.py:64-72: every encoder output feeds the next block and a decoder's skip input.  One alias per consumer
+    (no elementwise gradient sum by autograd; the BatchNorm-backward kernels read both gradients) must give exactly the
+    gradients of the single-tensor form."""
+    o1, g1 = _unet_grads(hs, alias=False)
+    o2, g2 = _unet_grads(hs, alias=True)
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+
+
+def test_convblock_per_op_path_equals_block_call(hs):
+    """the per-op Python launch sequence (bench.py's profiling path) == hipseg_convblock_forward/backward"""
+    from models.processing_blocks import ConvBlock, ConvBlockDownsample, ConvBlockUpsampleSkip
+
+    ops = hs.ops
+    cases = [(lambda: ConvBlock(64, 128), [(2, 64, 32, 32)]), (lambda: ConvBlockDownsample(32, 64), [(2, 32, 32, 32)]),
+             (lambda: ConvBlockUpsampleSkip(256, 128), [(2, 256, 16, 16), (2, 128, 32, 32)])]
+    for make, shapes in cases:
+        res = []
+        for per_op in (False, True):
+            torch.manual_seed(7)
+            m = make().cuda().train()
+            xs = [to_dev_nhwc(T(f"r4.blk{i}", sh), torch.bfloat16).requires_grad_(True) for i, sh in enumerate(shapes)]
+            old = ops._NO_BLOCK_CALLS
+            ops._NO_BLOCK_CALLS = per_op
+            try:
+                with torch.autocast("cuda"):
+                    y = m(*xs)
+                y.float().square().mean().backward()
+            finally:
+                ops._NO_BLOCK_CALLS = old
+            torch.cuda.synchronize()
+            res.append((y.detach(), [x.grad for x in xs], [p.grad.clone() for p in m.parameters()],
+                        [b.clone() for b in m.buffers()]))
+        (y0, gx0, gp0, b0), (y1, gx1, gp1, b1) = res
+        assert torch.equal(y0, y1)
+        for a, b in zip(gx0 + gp0 + b0, gx1 + gp1 + b1):
+            assert torch.equal(a, b)
+
+
+def test_conv2s2_with_bias_on_a_stream_shape_keeps_the_bias(hs):
+    """mode CONV2S2 (the ConvTranspose2d data gradient as a stride-2 2x2 convolution) through the public entry point with a
+    bias, on the shape the LDS-free streaming kernel takes for the U-Net (bf16, 32 input channels, 64 output channels, W
+    % 16 == 0): that kernel applies no bias in this mode, so the dispatch must route the call elsewhere."""
+    L, ops = hs.L, hs.ops
+    td, dt = torch.bfloat16, L.BF16
+    B, cout, cin, H, W = 2, 32, 64, 16, 32     # ConvT(cin -> cout): dy has cout channels at (2H, 2W), dx has cin at (H, W)
+    w = T("r4.tw", (cin, cout, 2, 2), -0.3, 0.3).cuda()
+    bias = T("r4.tb", (cin,), -0.5, 0.5).cuda()
+    dy = to_dev_nhwc(rnd(T("r4.tdy", (B, cout, 2 * H, 2 * W)), td), td)
+    wpt = ops._pack_convT(w, dt, True)
+    outs = []
+    for b in (None, bias):
+        dx = ops.nhwc_empty(B, cin, H, W, td, "cuda")
+        L.conv_igemm(dt, L.CONV2S2, ops.ptr(dy), cout, 0, 0, ops.ptr(wpt), ops.ptr(b), ops.ptr(dx), cin, 0, 0, 0, B, H, W,
+                     ops._stream())
+        torch.cuda.synchronize()
+        outs.append(dx.float())
+    ref = F.conv2d(dy.float().cpu(), rnd(w.cpu(), td).permute(0, 1, 2, 3), None, stride=2)  # (B, cin, H, W): w is (cin, cout, 2, 2)
+    assert (outs[0].cpu() - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+    diff = (outs[1] - outs[0]).cpu()
+    want = bias.cpu().view(1, -1, 1, 1).expand_as(diff)
+    assert (diff - want).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max())), "the bias was dropped"
+
+
+def test_profile_records_carry_bytes_for_hbm_groups(hs):
+    import models.UNet as un
+    from models.losses import HybridLoss
+
+    ops = hs.ops
+    m = un.UNet().cuda().train()
+    x = torch.rand(2, 3, 32, 32, device="cuda")
+    t = torch.randint(0, 3, (2, 32, 32), device="cuda")
+    ops.PROFILE = []
+    try:
+        with torch.autocast("cuda"):
+            loss = HybridLoss()(m(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        rec = list(ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+    keys = {r[0] for r in rec}
+    for k in ("hbm:bn_relu_apply", "hbm:bn_bwd_apply", "hbm:stem_fwd", "hbm:stem_bwd", "hbm:head_fwd", "hbm:head_bwd",
+              "hbm:ce_fwd", "hbm:ce_bwd", "hbm:bilinear_fwd"):
+        assert k in keys, (k, sorted(keys))
+    for key, flops, nbytes, e0, e1 in rec:
+        assert e0.elapsed_time(e1) >= 0.0
+        if key.startswith("hbm:"):
+            assert flops == 0.0 and nbytes > 0
+        else:
+            assert flops > 0
+    assert np.isfinite(float(loss.detach()))
