@@ -49,6 +49,8 @@ PROTOTYPES = {
     "hipseg_conv3_dgrad_bnstats": (I, [I, P, I, P, P, I, P, P, P, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
     "hipseg_conv_wgrad": (I, [I, I, P, I, P, I, P, I, P, P, I, I, I, P]),
+    "hipseg_convT_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I]),
+    "hipseg_convT_wgrad_bias": (I, [I, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_conv_wgrad_pair_applies": (I, [I, I, I, I, I, I, I, I]),
     "hipseg_conv_wgrad_pair": (I, [I, P, I, P, I, P, P, P, I, P, P, I, P, I, I, I, P]),
     "hipseg_bn_finalize": (I, [P, I, I, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
@@ -105,7 +107,7 @@ class ConvBlockArgs(ctypes.Structure):
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
-         "hipseg_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size",
+         "hipseg_wgrad_workspace_elems", "hipseg_convT_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size",
          "hipseg_convblock_size"}
 
 

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhipseg.so")
-SOURCES = ["pack.hip", "bn.hip", "pointwise.hip", "loss.hip", "records.hip", "augment.hip", "optim.hip", "sync.hip", "conv_igemm.hip", "conv3_m16.hip", "convt_stream.hip", "conv_wgrad.hip", "block.hip"]
+SOURCES = ["pack.hip", "bn.hip", "pointwise.hip", "loss.hip", "records.hip", "augment.hip", "optim.hip", "sync.hip", "conv_igemm.hip", "conv3_m16.hip", "convt_stream.hip", "conv_wgrad.hip", "convt_wgrad.hip", "block.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 

@@ -625,12 +625,13 @@ class ConvT2x2Fn(torch.autograd.Function):
         dev = x.device
         s = _stream()
         dy = as_nhwc(dy, x.dtype)
-        dw = grad_out(w)
-        _wgrad(dt, L.CONVT, dy, None, x, dw, B, H, W)
-        npix = B * 4 * H * W
-        part = _f32(L.colsum_blocks(npix, cout, dt) * cout, dev)
-        db = grad_out(ctx.bias)
-        _hbm("colsum(convT bias)", npix * cout * _esz(dt), L.colsum, dt, ptr(dy), npix, cout, ptr(part), ptr(db), s)
+        dw, db = grad_out(w), grad_out(ctx.bias)
+        # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY fragments its MFMAs
+        # hold): dY is read once, one reduction launch writes both parameters' layouts
+        work = _f32(L.convT_wgrad_workspace_elems(cin, cout, B, H, W), dev)
+        key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},CONVT>(+bias,+reduce)"
+        _timed(key, 2.0 * B * H * W * 4 * cout * cin, L.convT_wgrad_bias, dt, ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(work), B,
+               H, W, cin, cout, s, nbytes=float(B * H * W) * (4 * cout + cin) * _esz(dt))
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_convT(w, dt, True)

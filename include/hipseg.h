@@ -155,6 +155,19 @@ int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* 
                       const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
                       hipseg_stream_t stream);
 
+/* ConvTranspose2d(kernel 2, stride 2) backward w.r.t. weight AND bias in one MFMA kernel + one reduction launch:
+ *   dw[ci][co][a][b] = sum_{n,i,j} x[n,i,j,ci] * dy[n,2i+a,2j+b,co]   (fp32, (Cin, Cout, 2, 2), OVERWRITTEN)
+ *   db[co]           = sum_{n,y,x} dy[n,y,x,co]                       (fp32, (Cout), OVERWRITTEN)
+ * x: NHWC (B,H,W,Cin), dy: NHWC (B,2H,2W,Cout).  The bias gradient is the column sum of the dY fragments the weight
+ * gradient's MFMAs already hold -- dY is read once.  `work`: hipseg_convT_wgrad_workspace_elems(...) floats.  Shapes the
+ * fused kernel does not take (fp32; H % 8, W % 16, Cin % 8 or Cout % 8 != 0) run hipseg_conv_wgrad(HIPSEG_CONVT) followed
+ * by hipseg_colsum inside the same call.
+ * replaces: aten::convolution_backward (weight and bias gradients) of nn.ConvTranspose2d under autograd
+ *           (models/processing_blocks.py:102,106,128,132). */
+size_t hipseg_convT_wgrad_workspace_elems(int Cin, int Cout, int B, int H, int W);
+int hipseg_convT_wgrad_bias(int dtype, const void* dy, const void* x, float* dw, float* db, float* work, int B, int H,
+                            int W, int Cin, int Cout, hipseg_stream_t stream);
+
 /* The 3x3 weight gradients of the TWO convolutions of a ConvBlock (same pixel grid, same Cout = CV) in one launch +
  * one reduction launch: problem a = (pa0|pa1 dual source with CUa0 + CUa1 channels, qa = dY of the first conv) -> dwa
  * (CV, CUa0 + CUa1, 3, 3); problem b = (pb with CUb channels, qb = dY of the second conv) -> dwb (CV, CUb, 3, 3).

@@ -21,8 +21,13 @@ for name, B, ci, co, H in LAYERS:
     dw = torch.empty(ci, co, 2, 2, device="cuda")
     slabs = ops._f32(L.wgrad_workspace_elems(L.CONVT, co, ci, B, H, H), "cuda")
     s = torch.cuda.current_stream().cuda_stream
+    db = torch.empty(co, device="cuda")
+    work = ops._f32(L.convT_wgrad_workspace_elems(ci, co, B, H, H), "cuda")
+    part = ops._f32(L.colsum_blocks(B * 4 * H * H, co, dt) * co, "cuda")
     fns = {"fwd": lambda: ops.igemm(dt, L.CONVT, x, ci, None, 0, wp, b, y, co, None, 0, None, B, H, H),
            "dgrad": lambda: ops.igemm(dt, L.CONV2S2, dy, co, None, 0, wpt, None, dx, ci, None, 0, None, B, H, H),
+           "wgrad+bias (fused, round 4)": lambda: L.convT_wgrad_bias(dt, ops.ptr(dy), ops.ptr(x), ops.ptr(dw), ops.ptr(db), ops.ptr(work), B, H, H, ci, co, s),
+           "colsum(bias)": lambda: L.colsum(dt, ops.ptr(dy), B * 4 * H * H, co, ops.ptr(part), ops.ptr(db), s),
            "wgrad": lambda: L.conv_wgrad(dt, L.CONVT, ops.ptr(dy), co, 0, 0, ops.ptr(x), ci, ops.ptr(dw), ops.ptr(slabs), B, H, H, s)}
     for which, fn in fns.items():
         for _ in range(3):
@@ -35,4 +40,4 @@ for name, B, ci, co, H in LAYERS:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         mb = (x.numel() + y.numel()) * 2 / 1e6
-        print(f"convT {which:5s} {name:8s} {ms*1e3:8.1f} us  {mb/ms/1e3:6.2f} TB/s of activations  {2.0*B*H*H*ci*co*4/ms/1e9:8.1f} TF/s", flush=True)
+        print(f"convT {which:28s} {name:8s} {ms*1e3:8.1f} us  {mb/ms/1e3:6.2f} TB/s of activations  {2.0*B*H*H*ci*co*4/ms/1e9:8.1f} TF/s", flush=True)

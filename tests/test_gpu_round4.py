@@ -174,3 +174,41 @@ def test_profile_records_carry_bytes_for_hbm_groups(hs):
         else:
             assert flops > 0
     assert np.isfinite(float(loss.detach()))
+
+
+CONVT_WGRAD_CASES = [  # B, Cin, Cout, H, W   (x is H x W, dy is 2H x 2W)
+    (2, 512, 256, 16, 16),   # dec1.up's channel counts: 4 x 8 channel tiles, several pixel splits, XCD-ordered grid
+    (4, 64, 32, 32, 32),     # dec4.up's: one channel tile, every workgroup a pixel split
+    (1, 136, 40, 8, 16),     # ragged channel tiles on both sides (136 = 128 + 8 input channels, 160 = 128 + 32 columns)
+    (3, 128, 64, 24, 48),    # dec3.up's channel counts, non-square
+    (2, 64, 32, 6, 16),      # H % 8 != 0: the generic one-tap kernel + column sum inside the same entry point
+]
+
+
+@pytest.mark.parametrize("case", CONVT_WGRAD_CASES, ids=[str(c) for c in CONVT_WGRAD_CASES])
+def test_convT_weight_and_bias_gradient_in_one_kernel(hs, case):
+    """hipseg_convT_wgrad_bias (bf16) against autograd's ConvTranspose2d backward on the bf16-rounded operands (fp64 on
+    the CPU): dW (Cin, Cout, 2, 2) and db (Cout); bit-level determinism (fixed-order slab reduction)."""
+    L, ops = hs.L, hs.ops
+    B, Cin, Cout, H, W = case
+    td, dt = torch.bfloat16, L.BF16
+    x = rnd(T("r4.ctx", (B, Cin, H, W)), td)
+    dy = rnd(T("r4.ctdy", (B, Cout, 2 * H, 2 * W)), td)
+    w = torch.zeros(Cin, Cout, 2, 2, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double(), w, b, stride=2).backward(dy.double())
+    xd, dyd = to_dev_nhwc(x, td), to_dev_nhwc(dy, td)
+    work = torch.full((L.convT_wgrad_workspace_elems(Cin, Cout, B, H, W),), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cin, Cout, 2, 2), float("nan"), device="cuda")
+        db = torch.full((Cout,), float("nan"), device="cuda")
+        L.convT_wgrad_bias(dt, ops.ptr(dyd), ops.ptr(xd), ops.ptr(dw), ops.ptr(db), ops.ptr(work), B, H, W, Cin, Cout,
+                           ops._stream())
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    (dw, db), (dw2, db2) = outs
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    sw, sb = float(w.grad.abs().max()), float(b.grad.abs().max())
+    assert (dw.double() - w.grad).abs().max() <= 2e-5 * max(1.0, sw) * (B * H * W) ** 0.5
+    assert (db.double() - b.grad).abs().max() <= 2e-5 * max(1.0, sb) * (B * H * W) ** 0.5
