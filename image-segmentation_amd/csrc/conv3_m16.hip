@@ -19,6 +19,10 @@
 //   * The 16x16x32 shape holds a higher clock than 32x32x16 under load (MI355X_MICROARCH.md, DVFS give-back item 7).
 // Workgroup tile: THT x 16 output pixels (THT = 16 or 8 tile rows) x 128 channels; wave tile: all pixels x 32 channels.
 // Per (tap, stage) and wave: 2 weight loads, THT ds_read_b128, 2 * THT MFMAs.
+// NB = 2 (round 4): a 64-channel workgroup tile for layers whose output channel count is a multiple of 64 but not of 128
+// (128 -> 64 at 128 x 128 and its mirror data gradient in the U-Net; until round 4 they ran on conv_igemm.hip's ring
+// kernel at 0.30 of the MFMA peak): the four waves are 2 channel blocks x 2 halves of the tile's pixel rows, so a wave
+// still owns 32 channels and issues one ds_read_b128 per two MFMAs.
 #include <stdlib.h>
 
 #include "common.h"
@@ -62,12 +66,14 @@ struct M16Geo {
 // EPI: 0 = conv + bias (+ batch statistics rows when p.stats), 1 = inference epilogue relu(conv * scale + shift),
 //      2 = data gradient whose output is the dy of a BatchNorm+ReLU: besides storing it, reduce the BatchNorm-backward
 //          sums [sum g | sum g * xhat] (g = dy where relu(bn(x)) > 0) of the tile into p.stats (see the epilogue)
-template <int THT, int EPI>
+template <int THT, int EPI, int NB = 4>
 __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     typedef M16Geo<THT> G;
     typedef bf16 T;
     constexpr bool AFF = EPI == 1, BWS = EPI == 2;
+    constexpr int RS = 4 / NB, THW = THT / RS;  // pixel-row splits of the tile over the waves, tile rows per wave
+    static_assert(NB == 4 || NB == 2, "128- or 64-channel workgroup tiles");
     constexpr int NT = G::NT, D = G::D, PF = G::PF, HW = G::HW, NPIX = G::NPIX, NPIXA = G::NPIXA, NGRP = G::NGRP;
     constexpr int A_BYTES = G::A_BYTES, NPW = G::NPW;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
     const int tx = mtile % p.tiles_x;
     const int ty = (mtile / p.tiles_x) % p.tiles_y;
     const int img = mtile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty * THT, x0 = tx * 16, nw = ntile * G::BN + wave * 32;
+    const int wcol = wave % NB, rsp = wave / NB;  // the wave's 32-channel block and pixel-row part of the workgroup tile
+    const int y0 = ty * THT, x0 = tx * 16, nw = ntile * (32 * NB) + wcol * 32;
     const int nst = p.Kp / G::KS;
 
     const unsigned bytes0 = (unsigned)((size_t)p.B * p.Hi * p.Wi * p.C0 * sizeof(T));
@@ -164,14 +171,15 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         sc[k] = AFF ? p.post_scale[ch0 + k] : 1.f;
     }
 
-    f32x4 acc[2][THT];
+    f32x4 acc[2][THW];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int b = 0; b < THT; ++b) acc[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < THW; ++b) acc[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // B fragment of pixel block b (tile row b) at tap (ky, kx): halo pixel (b + ky) * HW + kx + li of octet plane lg
-    const unsigned abase = (unsigned)((lg * NPIXA + li) * 16);
+    // B fragment of pixel block b (tile row rsp * THW + b) at tap (ky, kx): halo pixel (row + ky) * HW + kx + li of octet
+    // plane lg
+    const unsigned abase = (unsigned)((lg * NPIXA + rsp * THW * HW + li) * 16);
 
     // ---- prologue: stages 0 and 1, the weights of the first D taps
 #pragma unroll
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         const int nslot = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3
         const int wst = s + 1 < nst ? s + 1 : s;       // weights of the wrapped taps (clamped: a harmless re-read)
         auto rdA = [&](int idx) {
-            const int tap = idx / THT, b = idx % THT;
+            const int tap = idx / THW, b = idx % THW;
             return *reinterpret_cast<const bf16x8*>(rd + ((b + tap / 3) * HW + tap % 3) * 16);
         };
         bf16x8 af[PF];
@@ -214,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             if (tap < NPW) pieceA(nslot, s + 2, tap, wave);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < THT; ++b) {
-                const int idx = tap * THT + b;
+            for (int b = 0; b < THW; ++b) {
+                const int idx = tap * THW + b;
 #ifdef HIPSEG_ABLATE
                 if (!(p.debug & 4))
 #endif
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
                     acc[0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[tap % (D + 1)][0], af[idx % PF], acc[0][b], 0, 0, 0);
                     acc[1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[tap % (D + 1)][1], af[idx % PF], acc[1][b], 0, 0, 0);
                 }
-                if (idx + PF < NT * THT) af[idx % PF] = rdA(idx + PF);
+                if (idx + PF < NT * THW) af[idx % PF] = rdA(idx + PF);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -275,20 +283,20 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             }
         }
         const T* rx = reinterpret_cast<const T*>(p.bw_x) + ch0;
-        constexpr int RB = THT < 8 ? THT : 8;  // rows of xr in flight per lane
+        constexpr int RB = THW < 8 ? THW : 8;  // rows of xr in flight per lane
 #pragma unroll
-        for (int b0 = 0; b0 < THT; b0 += RB) {
+        for (int b0 = 0; b0 < THW; b0 += RB) {
             bf16x8 xr[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int y = y0 + b0 + r;
+                const int y = y0 + rsp * THW + b0 + r;
                 const bool in = y < p.H && x < p.W;
                 const long pix = in ? (long)(img * p.H + y) * p.W + x : 0;
                 xr[r] = *reinterpret_cast<const bf16x8*>(rx + pix * p.N);
             }
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int b = b0 + r, y = y0 + b;
+                const int b = b0 + r, y = y0 + rsp * THW + b;
                 const bool in = y < p.H && x < p.W;
                 bf16x8 o;
 #pragma unroll
@@ -307,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
         }
     } else {
 #pragma unroll
-    for (int b = 0; b < THT; ++b) {
-        const int y = y0 + b;
+    for (int b = 0; b < THW; ++b) {
+        const int y = y0 + rsp * THW + b;
         const bool in = y < p.H && x < p.W;
         bf16x8 o;
 #pragma unroll
@@ -327,7 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
     }
     }
     if (p.stats) {
-        // one statistics row per workgroup tile; the 16 pixel columns of a channel sit in the 16 lanes of a row quad
+        // one statistics row per (workgroup tile, pixel-row part); the 16 pixel columns of a channel sit in the 16 lanes
+        // of a row quad
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
             }
         }
         if (li == 0) {
-            float* row = p.stats + (size_t)mtile * 2 * p.N + ch0;
+            float* row = p.stats + ((size_t)mtile * RS + rsp) * 2 * p.N + ch0;
             *reinterpret_cast<f32x4*>(row) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
             *reinterpret_cast<f32x4*>(row + 4) = f32x4{ssum[4], ssum[5], ssum[6], ssum[7]};
             *reinterpret_cast<f32x4*>(row + p.N) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
@@ -356,24 +365,24 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_kernel(ConvArgs p) {
 #endif
 }
 
-template <int THT>
+template <int THT, int NB>
 int launch_m16(const ConvArgs& a0, hipStream_t s) {
     typedef M16Geo<THT> G;
     ConvArgs a = a0;
     a.tiles_y = cdiv(a.H, THT);
-    a.ntn = a.Np / G::BN;
+    a.ntn = a.N / (32 * NB);  // (N, not the packed operand's Np: 192 channels are packed as 256 columns, the last 64 unused)
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     a.xcd = (grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
     const int threads = 256;
     if (a.bw_x) {
-        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 2>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, 2>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 2, NB>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 2, NB>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     } else if (a.post_scale) {
-        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 1>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, 1>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 1, NB>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 1, NB>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     } else {
-        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 0>), (size_t)G::LDS)) return rc;
-        hipLaunchKernelGGL((conv3_m16_kernel<THT, 0>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_m16_kernel<THT, 0, NB>), (size_t)G::LDS)) return rc;
+        hipLaunchKernelGGL((conv3_m16_kernel<THT, 0, NB>), dim3((unsigned)grid), dim3(threads), G::LDS, s, a);
     }
     HS_LAUNCH_CHECK("conv3_m16");
     return HIPSEG_OK;
@@ -386,19 +395,22 @@ int conv3_m16_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, i
     static const bool off = getenv("HIPSEG_NO_M16") != nullptr || getenv("HIPSEG_NO_DMA") != nullptr;
     if (off || dtype != HIPSEG_BF16 || mode != HIPSEG_CONV3) return 0;
     const int K = C0 + C1, N = N0 + N1;
-    if (N % 128 || K % 32 || (C1 && C0 % 32) || N0 % 8 || N1 % 8) return 0;
+    static const bool no64 = getenv("HIPSEG_NO_M16_BN64") != nullptr;  // A/B switch: 64-channel tiles to the ring kernel
+    if (N % 64 || (N % 128 && no64) || K % 32 || (C1 && C0 % 32) || N0 % 8 || N1 % 8) return 0;
     // buffer addressing: byte offsets below 2^30 (2^31 marks an out-of-range lane)
     const size_t in_bytes = (size_t)B * H * W * (size_t)(C0 > C1 ? C0 : C1) * 2, w_bytes = (size_t)9 * K * N * 2;
     if (in_bytes > ((size_t)1 << 30) || w_bytes > ((size_t)1 << 30)) return 0;
     // 16-row tiles when they give every CU its two workgroups, else 8-row tiles (twice the grid)
-    const long wgs16 = (long)B * cdiv(W, 16) * cdiv(H, 16) * (N / 128);
+    const long wgs16 = (long)B * cdiv(W, 16) * cdiv(H, 16) * (N % 128 ? N / 64 : N / 128);
     static const char* force = getenv("HIPSEG_M16_ROWS");
     if (force) return atoi(force) == 8 ? 8 : 16;
     return wgs16 >= 2 * (long)device_cus() ? 16 : 8;
 }
 
-int conv3_m16_stats_rows(int rows, int B, int H, int W) { return B * cdiv(W, 16) * cdiv(H, rows); }
+// statistics rows of a launch: one per tile of `rows` x 16 pixels, two (the tile's pixel-row halves) with 64-channel tiles
+int conv3_m16_stats_rows(int rows, int N, int B, int H, int W) { return B * cdiv(W, 16) * cdiv(H, rows) * (N % 128 ? 2 : 1); }
 
 int conv3_m16_launch(const ConvArgs& a, int rows, hipStream_t s) {
-    return rows == 16 ? launch_m16<16>(a, s) : launch_m16<8>(a, s);
+    if (a.N % 128) return rows == 16 ? launch_m16<16, 2>(a, s) : launch_m16<8, 2>(a, s);
+    return rows == 16 ? launch_m16<16, 4>(a, s) : launch_m16<8, 4>(a, s);
 }

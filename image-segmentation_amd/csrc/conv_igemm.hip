@@ -32,7 +32,7 @@
 
 // 16x16x32-MFMA kernel for the >= 128-channel 3x3 layers (conv3_m16.hip)
 int conv3_m16_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
-int conv3_m16_stats_rows(int rows, int B, int H, int W);
+int conv3_m16_stats_rows(int rows, int N, int B, int H, int W);
 int conv3_m16_launch(const ConvArgs& a, int rows, hipStream_t s);
 // LDS-free streaming kernel for the small-channel ConvTranspose2d stages (convt_stream.hip)
 int convt_stream_applies(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W);
@@ -1478,7 +1478,7 @@ extern "C" int hipseg_conv_mtiles(int B, int H, int W) { return 4 * B * cdiv(H, 
 extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N0, int N1, int B, int H, int W) {
     const int g = wstat_grid(dtype, mode, C0, C1, N0, N1, B, H, W);
     if (g) return g * (N0 + N1 == 64 ? 2 : 4);  // one row per (workgroup, pixel-row wave group)
-    if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_stats_rows(r16, B, H, W);
+    if (const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W)) return conv3_m16_stats_rows(r16, N0 + N1, B, H, W);
     return hipseg_conv_mtiles(B, H, W);
 }
 
@@ -1612,7 +1612,7 @@ extern "C" int hipseg_conv3_dgrad_bnstats_rows(int dtype, int C, int N, int B, i
     if (off) return 0;
     if (wstat_grid(dtype, HIPSEG_CONV3, C, 0, N, 0, B, H, W)) return 0;  // (that kernel has no such epilogue)
     const int r16 = conv3_m16_rows(dtype, HIPSEG_CONV3, C, 0, N, 0, B, H, W);
-    return r16 ? conv3_m16_stats_rows(r16, B, H, W) : 0;
+    return r16 ? conv3_m16_stats_rows(r16, N, B, H, W) : 0;
 }
 
 extern "C" int hipseg_conv3_dgrad_bnstats(int dtype, const void* dy, int C, const void* wp, void* out, int N, const void* x,

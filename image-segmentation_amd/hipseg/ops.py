@@ -569,6 +569,10 @@ class ConvBlockFn(torch.autograd.Function):
             wp2t = _pack_conv(w2, dt, True)
         da1 = nhwc_empty(B, C, H, W, raw2.dtype, dev)
         rows = L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W)
+        # (the same rule as hipseg_convblock_backward: the fused epilogue only when its rows fit the `partial` workspace
+        # as include/hipseg.h sizes it -- the reduce kernels' block counts)
+        if rows > max(L.bn_bwd_blocks(B, H, W, C, dt, 0), L.bn_bwd_blocks(B, H, W, C, dt, 1) if pool else 0):
+            rows = 0
         reduced = None
         if rows:
             partial = _f32(rows * 2 * C, dev)

@@ -80,6 +80,13 @@ CONV_CASES = [
     (1, 512, 0, 512, 16, 16),
     (2, 128, 0, 384, 16, 32),
     (16, 32, 0, 128, 64, 64),
+    # N % 64 == 0 but not % 128, K % 32 == 0: the same kernel with 64-channel workgroup tiles (round 4: two channel blocks
+    # x two pixel-row halves per workgroup) -- 16- and 8-row tiles, dual source, the mirror data gradient with a dual
+    # destination, three channel tiles, ragged borders
+    (4, 128, 0, 64, 64, 64),
+    (1, 64, 64, 64, 20, 36),
+    (2, 96, 0, 192, 17, 33),
+    (16, 128, 0, 64, 32, 32),
     # >= 1024 tiles of 8x16 pixels with <= 64 channels: the weights-stationary persistent kernel (all four
     # K/N shapes between fwd and dgrad, dual source / dual destination, ragged image borders)
     (2, 64, 0, 64, 256, 256),
@@ -220,7 +227,8 @@ def test_convT(hs, prec, td, dt, case):
 
 # B, C (= K = N), H, W: the second conv of a ConvBlock at the U-Net's >= 128-channel levels (16- and 8-row tiles, ragged
 # borders, several channel tiles)
-DGRAD_BNSTATS_CASES = [(2, 128, 32, 32), (1, 256, 20, 36), (4, 128, 64, 64), (1, 512, 16, 16), (2, 128, 9, 17)]
+DGRAD_BNSTATS_CASES = [(2, 128, 32, 32), (1, 256, 20, 36), (4, 128, 64, 64), (1, 512, 16, 16), (2, 128, 9, 17),
+                       (2, 192, 24, 40), (8, 192, 32, 32)]  # (64-channel tiles: two statistics rows per tile)
 
 
 @pytest.mark.parametrize("case", DGRAD_BNSTATS_CASES, ids=[str(c) for c in DGRAD_BNSTATS_CASES])
