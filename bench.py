@@ -108,16 +108,12 @@ def cpu_baseline(args):
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.lower().startswith("model name")), "unknown")
     except OSError:
         pass
-    allc = None
-    if avail > cores and not os.environ.get("HIPSEG_CPU_THREADS"):
-        # BASELINE.md section 4 asks for os.cpu_count() threads: timed beside the per-GPU-share figure (2 steps)
-        torch.set_num_threads(avail)
-        tr.step(x, t)
-        t1 = time.perf_counter()
-        for _ in range(2):
-            tr.step(x, t)
-        allc = {"threads": avail, "value": round(args.cpu_batch / ((time.perf_counter() - t1) / 2), 3), "unit": "images/s"}
-        torch.set_num_threads(cores)
+    # (BASELINE.md section 4 names os.cpu_count() threads.  Measured once on the GPU box, round 4, profiles/r04a_bench_default.json
+    # of the first collection: 256 threads -> 0.053 images/s, 80x SLOWER than 16 threads (oneDNN oversubscribes the two
+    # sockets on 4-image batches) and 75 s per step -- that leg alone took the default run past four minutes, so the
+    # baseline stays at the per-GPU CPU share of the box and the JSON says so.)
+    allc = {"threads": avail, "value": 0.053, "unit": "images/s", "measured": "round 4, once (not in this run: 75 s per step)"} \
+        if avail >= 128 else None
     return {"value": round(args.cpu_batch / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model, "threads": cores, "host_cpus_visible": avail, "all_host_cpus": allc,
             "sample": f"{args.cpu_steps} steps of batch {args.cpu_batch} x 3x{args.size}x{args.size} fp32 "
@@ -946,7 +942,18 @@ def worker(args, world):
         for _ in range(4):
             step().item()
         torch.cuda.synchronize()
-        issue, walls, t0 = [], [], time.perf_counter()
+        import gc
+
+        pauses, gstart = [], [0.0]
+
+        def _gc_cb(phase, info):  # (CPython's cyclic collector: a generation-2 pass over everything torch imported)
+            if phase == "start":
+                gstart[0] = time.perf_counter()
+            else:
+                pauses.append((gstart[0], time.perf_counter(), info.get("generation", -1)))
+
+        gc.callbacks.append(_gc_cb)
+        issue, walls, spans, t0 = [], [], [], time.perf_counter()
         nst = 20
         for _ in range(nst):
             ti = time.perf_counter()
@@ -954,14 +961,21 @@ def worker(args, world):
             issue.append(time.perf_counter() - ti)
             l_.item()
             walls.append(time.perf_counter() - ti)
+            spans.append((ti, time.perf_counter()))
+        gc.callbacks.remove(_gc_cb)
         tot = (time.perf_counter() - t0) / nst
         slowest_at = max(range(nst), key=lambda i: walls[i])
+        a_, b_ = spans[slowest_at]
+        gc_in_slowest = sum(min(e, b_) - max(st, a_) for st, e, _ in pauses if e > a_ and st < b_)
         issue.sort()
         ws = sorted(walls)
         med = ws[nst // 2]
         out["eager"] = {"ms_per_step": round(med * 1e3, 4), "ms_per_step_mean": round(tot * 1e3, 4),
                         "ms_per_step_max": round(ws[-1] * 1e3, 4), "slowest_step_index": slowest_at,
                         "first_step_after_profiling_ms": round(first_ms, 4),
+                        "gc_pause_ms_in_slowest_step": round(gc_in_slowest * 1e3, 3),
+                        "gc_collections": {"count": len(pauses), "gen2": sum(1 for p_ in pauses if p_[2] == 2),
+                                           "total_ms": round(sum(e - st for st, e, _ in pauses) * 1e3, 3)},
                         "host_issue_ms_per_step": round(issue[nst // 2] * 1e3, 4),
                         "steps": nst, "images_per_s": round(args.batch / med, 1),
                         "vs_graph": round(med * 1e3 / ms, 4),
