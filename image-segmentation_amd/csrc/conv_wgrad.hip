@@ -554,7 +554,11 @@ struct Tr16Geo {
 // (workgroups x 147 KB of fp32 partial sums, written here and read back by the reduction) of BOTH layers together is
 // what ONE layer's was.  The grid is padded to a multiple of 8 and dealt to the XCDs in contiguous runs of logical
 // ids (s-major), so the workgroups of one pixel split share an L2.
-template <bool PAIR>
+// RAGGED (round 4): H or W not a multiple of 16 (ClipUnet-224's 56 x 56 and 28 x 28 levels).  The tile grid is rounded up
+// and a lane whose pixel lies beyond the image's bottom / right edge does not fetch (zero fill: it contributes nothing):
+// its halo coordinates are two more per-lane constants per piece, compared with two per-tile limits.  A separate
+// instantiation, so the whole-tile kernels of the U-Nets keep their 3-instruction pieces.
+template <bool PAIR, bool RAGGED = false>
 __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2, int tA, int tB) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef Tr16Geo G;
@@ -611,9 +615,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
     const unsigned colsrc = (unsigned)((((slot >> 1) ^ ((prow >> 1) & 3)) << 1) | (slot & 1)) * 16u;
     // 5 flags per P piece: halo pixel in the top / bottom halo row, left / right halo column, lane beyond the halo tile
     unsigned pofs[NPW_P], qofs[NPW_Q], pflags = 0;
+    unsigned pyx[RAGGED ? NPW_P : 1];  // RAGGED: halo row | halo column << 8 of the lane's pixel of piece j
 #pragma unroll
     for (int j = 0; j < NPW_P; ++j) {
         const int hp = (j * NW + wave) * 8 + prow, dy = hp / PHW, dx = hp - dy * PHW;
+        if (RAGGED) pyx[j] = (unsigned)(dy | (dx << 8));
         pofs[j] = (unsigned)((dy * a.W + dx) * cstrideP) + colsrc;
         const unsigned f = hp < NPP ? (unsigned)((dy == 0) | ((dy == G::TH + 1) << 1) | ((dx == 0) << 2) | ((dx == PHW - 1) << 3)) : 16u;
         pflags |= f << (5 * j);
@@ -640,13 +646,19 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
     // side k lies outside the image; bit 4 always set: lanes beyond the halo tile never fetch)
     struct TileS {
         unsigned soP, soQ, edge;
+        int ylim, xlim;  // RAGGED: first halo row / column beyond the image (H - y0 + 1, W - x0 + 1)
+        bool qcolok;     // RAGGED: this lane's Q tile column is inside the image
     };
+    const int qcol = 8 * (wave & 1) + prow, qrow0 = wave >> 1;  // Q piece j holds tile row 4 j + qrow0, column qcol
     auto tile_scalars = [&](int img, int y0, int x0) {
         TileS t;
         const unsigned pix = (unsigned)((img * a.H + y0) * a.W + x0);
         t.soP = pix * (unsigned)cstrideP + soP;
         t.soQ = pix * (unsigned)cstrideQ + soQ;
         t.edge = (unsigned)((y0 == 0) | ((y0 + G::TH >= a.H) << 1) | ((x0 == 0) << 2) | ((x0 + TW >= a.W) << 3)) | 16u;
+        t.ylim = a.H - y0 + 1;
+        t.xlim = a.W - x0 + 1;
+        t.qcolok = qcol < a.W - x0;
         return t;
     };
     // piece j (0 .. NPW - 1) into ring slot `base` (absolute LDS byte address)
@@ -655,11 +667,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
             const int pc = j * NW + wave;
             const bool real = (j + 1) * NW <= NPC_P || pc < NPC_P;  // wave-uniform
             const unsigned hit = pflags & (t.edge << (5 * j));
-            const unsigned vo = hit ? OOB : pofs[j];
+            bool bad = hit != 0;
+            if (RAGGED) bad = bad || (int)(pyx[j] & 0xffu) >= t.ylim || (int)(pyx[j] >> 8) >= t.xlim;
+            const unsigned vo = bad ? OOB : pofs[j];
             if (real) dma_piece(r_p, base + pc * 1024, vo, t.soP);
         } else {
             const int pc = (j - NPW_P) * NW + wave;
-            dma_piece(r_q, base + PP_BYTES + pc * 1024, qofs[j - NPW_P], t.soQ);
+            unsigned vo = qofs[j - NPW_P];
+            if (RAGGED) vo = (t.qcolok && 4 * (j - NPW_P) + qrow0 < t.ylim - 1) ? vo : OOB;
+            dma_piece(r_q, base + PP_BYTES + pc * 1024, vo, t.soQ);
         }
     };
 
@@ -839,17 +855,28 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
 }
 
 int launch_tr16(const WgArgs& a, hipStream_t s) {
-    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false>), (size_t)Tr16Geo::LDS)) return rc;
-    hipLaunchKernelGGL(wgrad3_tr16_kernel<false>, dim3((unsigned)(a.S * a.UT * a.VT)), dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
+    const dim3 grid((unsigned)(a.S * a.UT * a.VT));
+    if (a.H % 16 || a.W % 16) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false, true>), (size_t)Tr16Geo::LDS)) return rc;
+        hipLaunchKernelGGL((wgrad3_tr16_kernel<false, true>), grid, dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
+    } else {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false>), (size_t)Tr16Geo::LDS)) return rc;
+        hipLaunchKernelGGL(wgrad3_tr16_kernel<false>, grid, dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
+    }
     HS_LAUNCH_CHECK("conv_wgrad_tr16");
     return HIPSEG_OK;
 }
 
 int launch_tr16_pair(const WgArgs& a, const WgArgs& b, hipStream_t s) {
-    if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<true>), (size_t)Tr16Geo::LDS)) return rc;
     const int tA = a.UT * a.VT, tB = b.UT * b.VT;
     const int grid = (a.S * (tA + tB) + 7) / 8 * 8;
-    hipLaunchKernelGGL(wgrad3_tr16_kernel<true>, dim3((unsigned)grid), dim3(512), Tr16Geo::LDS, s, a, b, tA, tB);
+    if (a.H % 16 || a.W % 16) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<true, true>), (size_t)Tr16Geo::LDS)) return rc;
+        hipLaunchKernelGGL((wgrad3_tr16_kernel<true, true>), dim3((unsigned)grid), dim3(512), Tr16Geo::LDS, s, a, b, tA, tB);
+    } else {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<true>), (size_t)Tr16Geo::LDS)) return rc;
+        hipLaunchKernelGGL(wgrad3_tr16_kernel<true>, dim3((unsigned)grid), dim3(512), Tr16Geo::LDS, s, a, b, tA, tB);
+    }
     HS_LAUNCH_CHECK("conv_wgrad_tr16(pair)");
     return HIPSEG_OK;
 }
@@ -1066,8 +1093,9 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     for (int ab = 0; ab < 1; ++ab) {
         int rc;
         static const bool no_tr16 = getenv("HIPSEG_NO_WGRAD_TR16") != nullptr;  // A/B switch
-        const bool tr16 = dma && !no_tr16 && !dbg && mode == HIPSEG_CONV3 && CU % 64 == 0 && CV % 64 == 0 && H % 16 == 0 &&
-                          W % 16 == 0 &&
+        static const bool no_ragged = getenv("HIPSEG_NO_WGRAD_RAGGED") != nullptr;  // A/B switch: whole tiles only
+        const bool tr16 = dma && !no_tr16 && !dbg && mode == HIPSEG_CONV3 && CU % 64 == 0 && CV % 64 == 0 &&
+                          ((H % 16 == 0 && W % 16 == 0) || !no_ragged) &&
                           (CU1 == 0 || CU0 % 64 == 0) &&
                           (size_t)B * H * W * (size_t)(CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1)) * 2 <= ((size_t)1 << 30);
         if (tr16)
@@ -1122,7 +1150,8 @@ namespace {
 bool tr16_shape_ok(int CU0, int CU1, int CV, int B, int H, int W) {
     const int CU = CU0 + CU1;
     const int cmax = CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1);
-    return CU % 64 == 0 && CV % 64 == 0 && H % 16 == 0 && W % 16 == 0 && (CU1 == 0 || CU0 % 64 == 0) &&
+    static const bool no_ragged = getenv("HIPSEG_NO_WGRAD_RAGGED") != nullptr;  // A/B switch: whole tiles only
+    return CU % 64 == 0 && CV % 64 == 0 && ((H % 16 == 0 && W % 16 == 0) || !no_ragged) && (CU1 == 0 || CU0 % 64 == 0) &&
            (size_t)B * H * W * (size_t)cmax * 2 <= ((size_t)1 << 30);
 }
 
@@ -1134,14 +1163,23 @@ int pair_splits(int dtype, int CUa0, int CUa1, int CUb, int CV, int B, int H, in
     if (!tr16_shape_ok(CUa0, CUa1, CV, B, H, W) || !tr16_shape_ok(CUb, 0, CV, B, H, W)) return 0;
     const int tA = ((CUa0 + CUa1) / 64) * (CV / 64), tB = (CUb / 64) * (CV / 64);
     const int ncu = device_cus();
-    const int ntiles = B * (H / 16) * (W / 16);
+    const int ntiles = B * cdiv(H, 16) * cdiv(W, 16);
     int S = ncu / (tA + tB);
     // worth it when the paired grid still fills the chip (>= 90 % of the CUs; alone each layer fills it) and every
     // layer would have been split at least twice on its own (otherwise there is little slab traffic to save); a pixel
     // grid with fewer tiles than that caps the split count of either form, the pair then only adds workgroups
     if (S < 1 || ncu / tA < 2 || ncu / tB < 2) return 0;
-    if (S >= ntiles) return ntiles;
-    if ((long)S * (tA + tB) * 10 < (long)ncu * 9) return 0;
+    if (S >= ntiles) S = ntiles;
+    else if ((long)S * (tA + tB) * 10 < (long)ncu * 9) return 0;
+    // Both layers' slabs live in the ONE workspace the caller sized with hipseg_wgrad_workspace_elems() of either layer
+    // (include/hipseg.h).  With enough tiles the pair's S * (tA + tB) tile slabs are at most the CU count, like a single
+    // layer's; when the TILE count caps the splits (small images) the pair needs S slabs of BOTH layers, more than
+    // either layer's own S -- such shapes are not paired (round 4: found as a GPU fault on a 2 x 16 x 24 level once
+    // ragged grids reached this path; whole-tile grids of few tiles had been writing past the workspace unnoticed).
+    const size_t need = (size_t)S * 9 * (size_t)(CUa0 + CUa1 + CUb) * CV;
+    const size_t wa = hipseg_wgrad_workspace_elems(HIPSEG_CONV3, CUa0 + CUa1, CV, B, H, W);
+    const size_t wb = hipseg_wgrad_workspace_elems(HIPSEG_CONV3, CUb, CV, B, H, W);
+    if (need > (wa > wb ? wa : wb)) return 0;
     return S;
 }
 
@@ -1168,8 +1206,8 @@ WgArgs tr16_args(const void* p0, int CU0, const void* p1, int CU1, const void* q
     a.PW = W;
     a.pa = 0;
     a.pb = 0;
-    a.tiles_x = W / 16;
-    a.tiles_y = H / 16;
+    a.tiles_x = cdiv(W, 16);  // (ragged edges: wgrad3_tr16_kernel<PAIR, RAGGED = true>)
+    a.tiles_y = cdiv(H, 16);
     a.ntiles = B * a.tiles_x * a.tiles_y;
     a.S = S;
     a.vec_ok_p = 1;

@@ -95,19 +95,32 @@ __global__ __launch_bounds__(512, 1) void convt_wgrad_kernel(TwArgs a) {
         nty -= cy ? a.tiles_y : 0;
         nimg += si + cy;
     };
+    // Ragged image edges (H % 8 or W % 16 != 0: ClipUnet's 28 x 28 and 56 x 56 stages): a pixel of the tile that lies
+    // outside the image must contribute nothing to dW and to the dY column sums, so its lanes do not fetch (zero fill).
+    // The pixel of a lane is (row 2 j + (wave >> 2), column (4 wave + prow) & 15) of the tile: the column is a per-lane
+    // constant (one compare per tile), the row is wave-uniform (a scalar compare per piece).
+    const int lcol = (4 * wave + prow) & 15, lrow0 = wave >> 2;
     struct TileS {
         unsigned soP, soQ;
+        int rows;     // tile rows inside the image
+        bool colok;   // this lane's tile column is inside the image
     };
     auto tile_scalars = [&]() {
         TileS t;
         const int y0 = nty * G::TH, x0 = ntx * G::TW;
         t.soP = (unsigned)(((nimg * a.H + y0) * a.W + x0) * cstrideP + u0 * 2);
         t.soQ = (unsigned)((nimg * 2 * a.H + 2 * y0) * rowQ + x0 * cstrideQ);
+        t.rows = a.H - y0;
+        t.colok = lcol < a.W - x0;
         return t;
     };
-    auto pieceP = [&](int j, unsigned base, const TileS& t) { dma_piece(r_p, base + (j * G::NW + wave) * 1024, pofs[j], t.soP); };
+    auto pieceP = [&](int j, unsigned base, const TileS& t) {
+        const bool ok = t.colok && 2 * j + lrow0 < t.rows;
+        dma_piece(r_p, base + (j * G::NW + wave) * 1024, ok ? pofs[j] : OOB, t.soP);
+    };
     auto pieceQ = [&](int j, unsigned base, const TileS& t) {
-        dma_piece(r_q, base + IMG + (j * G::NW + wave) * 1024, qofs[j], t.soQ);
+        const bool ok = t.colok && 2 * j + lrow0 < t.rows;
+        dma_piece(r_q, base + IMG + (j * G::NW + wave) * 1024, ok ? qofs[j] : OOB, t.soQ);
     };
 
     // ---- fragment addresses (absolute LDS addresses).  Transposed read: 16-lane group g = lane >> 4 is k octet g; its
@@ -301,8 +314,8 @@ TwPlan tw_plan(int Cin, int Cout, int B, int H, int W) {
     p.VT = cdiv(4 * Cout, TwGeo::VC);
     p.CUp = p.UT * TwGeo::UC;
     p.CVp = p.VT * TwGeo::VC;
-    p.tiles_x = W / TwGeo::TW;
-    p.tiles_y = H / TwGeo::TH;
+    p.tiles_x = cdiv(W, TwGeo::TW);
+    p.tiles_y = cdiv(H, TwGeo::TH);
     p.ntiles = B * p.tiles_x * p.tiles_y;
     int S = device_cus() / (p.UT * p.VT);
     if (S < 1) S = 1;
@@ -313,7 +326,7 @@ TwPlan tw_plan(int Cin, int Cout, int B, int H, int W) {
 
 bool tw_applies(int dtype, int Cin, int Cout, int B, int H, int W) {
     static const bool off = getenv("HIPSEG_NO_CONVT_WGRAD") != nullptr;  // A/B switch: generic one-tap kernel + column sum
-    if (off || dtype != HIPSEG_BF16 || Cin % 8 || Cout % 8 || H % TwGeo::TH || W % TwGeo::TW) return false;
+    if (off || dtype != HIPSEG_BF16 || Cin % 8 || Cout % 8) return false;
     const size_t xb = (size_t)B * H * W * Cin * 2, yb = (size_t)B * 4 * H * W * Cout * 2;
     return xb <= ((size_t)1 << 30) && yb <= ((size_t)1 << 30);
 }
@@ -323,7 +336,7 @@ bool tw_applies(int dtype, int Cin, int Cout, int B, int H, int W) {
 extern "C" size_t hipseg_convT_wgrad_workspace_elems(int Cin, int Cout, int B, int H, int W) {
     // the fused kernel's slabs + column sums, or (shapes it does not take) the generic weight gradient's slabs followed by
     // the column-sum partials
-    const TwPlan p = tw_plan(Cin, Cout, B, H > 0 ? H : 1, W > 0 ? W : 1);
+    const TwPlan p = tw_plan(Cin, Cout, B, H, W);
     const size_t fused = (size_t)p.S * p.CUp * p.CVp + (size_t)p.S * p.CVp;
     size_t generic = hipseg_wgrad_workspace_elems(HIPSEG_CONVT, Cout, Cin, B, H, W);
     for (int dt = 0; dt < 2; ++dt) {

@@ -160,8 +160,8 @@ int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* 
  *   db[co]           = sum_{n,y,x} dy[n,y,x,co]                       (fp32, (Cout), OVERWRITTEN)
  * x: NHWC (B,H,W,Cin), dy: NHWC (B,2H,2W,Cout).  The bias gradient is the column sum of the dY fragments the weight
  * gradient's MFMAs already hold -- dY is read once.  `work`: hipseg_convT_wgrad_workspace_elems(...) floats.  Shapes the
- * fused kernel does not take (fp32; H % 8, W % 16, Cin % 8 or Cout % 8 != 0) run hipseg_conv_wgrad(HIPSEG_CONVT) followed
- * by hipseg_colsum inside the same call.
+ * fused kernel does not take (fp32; Cin % 8 or Cout % 8 != 0) run hipseg_conv_wgrad(HIPSEG_CONVT) followed by
+ * hipseg_colsum inside the same call.
  * replaces: aten::convolution_backward (weight and bias gradients) of nn.ConvTranspose2d under autograd
  *           (models/processing_blocks.py:102,106,128,132). */
 size_t hipseg_convT_wgrad_workspace_elems(int Cin, int Cout, int B, int H, int W);

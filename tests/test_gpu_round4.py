@@ -181,7 +181,10 @@ CONVT_WGRAD_CASES = [  # B, Cin, Cout, H, W   (x is H x W, dy is 2H x 2W)
     (4, 64, 32, 32, 32),     # dec4.up's: one channel tile, every workgroup a pixel split
     (1, 136, 40, 8, 16),     # ragged channel tiles on both sides (136 = 128 + 8 input channels, 160 = 128 + 32 columns)
     (3, 128, 64, 24, 48),    # dec3.up's channel counts, non-square
-    (2, 64, 32, 6, 16),      # H % 8 != 0: the generic one-tap kernel + column sum inside the same entry point
+    (2, 64, 32, 6, 16),      # H % 8 != 0: ragged bottom tile rows
+    (2, 256, 128, 28, 28),   # ClipUnet-224's dec2.up geometry: ragged on both axes (28 = 3.5 x 8 = 1.75 x 16)
+    (1, 128, 64, 5, 7),      # an image smaller than one tile
+    (2, 12, 6, 8, 16),       # Cin % 8 != 0: the generic one-tap kernel + column sum inside the same entry point
 ]
 
 
