@@ -454,57 +454,6 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        // The contributors of each axis first (index arithmetic only), then the loads: when down-scaling (s >= 1, the
-        // U-Net's dec1 resize) an input pixel is sampled by at most two outputs per axis, so the gather is at most
-        // 2 x 2 loads, all issued before the first use (inside the candidate loops every load sat behind two
-        // data-dependent branches: one 16-byte load in flight per lane, 19 us for a 42-MB pass).  Same summation
-        // order as the generic loops below (row-major over the contributors), which remain for up-scaling windows.
-        int cy[2] = {0, 0}, cx[2] = {0, 0}, ny = 0, nx = 0;
-        float wy2[2] = {0.f, 0.f}, wx2[2] = {0.f, 0.f};
-        for (int jy = jy0; jy <= jy1; ++jy) {
-            int a0, a1;
-            float l0, l1;
-            src_index(sy, jy, Hi, a0, a1, l0, l1);
-            const float wy = (a0 == iy ? l0 : 0.f) + (a1 == iy ? l1 : 0.f);
-            if (wy != 0.f) {
-                if (ny < 2) {
-                    cy[ny] = jy;
-                    wy2[ny] = wy;
-                }
-                ++ny;
-            }
-        }
-        for (int jx = jx0; jx <= jx1; ++jx) {
-            int b0, b1;
-            float m0, m1;
-            src_index(sx, jx, Wi, b0, b1, m0, m1);
-            const float wx = (b0 == ix ? m0 : 0.f) + (b1 == ix ? m1 : 0.f);
-            if (wx != 0.f) {
-                if (nx < 2) {
-                    cx[nx] = jx;
-                    wx2[nx] = wx;
-                }
-                ++nx;
-            }
-        }
-        if (ny <= 2 && nx <= 2) {
-            float g[2][2][V];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) ldv<T, V>(dy + ((n * Ho + cy[a]) * Wo + cx[b]) * C + cg * V, g[a][b]);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const bool on = a < ny && b < nx;
-                    const float w = wy2[a] * wx2[b];
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e] = on ? fmaf(w, g[a][b][e], acc[e]) : acc[e];
-                }
-            stv<T, V>(dx + ip * C + cg * V, acc);
-            continue;
-        }
         for (int jy = jy0; jy <= jy1; ++jy) {
             int a0, a1;
             float l0, l1;
