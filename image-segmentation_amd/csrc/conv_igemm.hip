@@ -1063,11 +1063,22 @@ struct WsGeo {
     static constexpr int WM = NW / NB, MT = (THS / 2) / WM;         // NB = 2: 2 x 2 waves, MT 2;  NB = 1: 4 x 1, MT 1
     static constexpr int NACC = MT == 1 ? 2 : MT;                   // MT 1: two accumulators break the MFMA chain
     static constexpr int DEPTH = MT == 1 ? 4 : 3;                   // fragment prefetch ring (steps)
-    static constexpr int SCR = 1024;                                // per-wave bf16 [16 px][32 ch] transpose tile
+    static constexpr int SCR = 2048;                                // per-wave: two bf16 [16 px][32 ch] transpose tiles
     static constexpr size_t LDS = (size_t)NBUF * A_BYTES + NW * SCR;
     static constexpr int NST = 2 * MT;                              // output stores per wave per tile
     static_assert(NOCT % NW == 0 && LDS <= 80 * 1024, "geometry");
 };
+
+#ifdef WS_STAMP
+// diagnostic build only (scripts/build_variant.sh wsstamp conv_igemm.hip -DWS_STAMP): per-workgroup cycle sums of the
+// tile loop's phases (wave 0) into a buffer nothing else reads
+}  // namespace
+__device__ unsigned long long g_ws_stamp[1024 * 8];
+extern "C" int hipseg_debug_ws_stamps(void* host, int nwg) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_stamp), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 template <int KCH, int NB, bool DBG, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int total_tiles, int tiles_y8) {
@@ -1190,7 +1201,14 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
     float ssum = 0.f, ssq = 0.f;
     int cur = 0;
     int hist = 0;                // bit k: the tile k+1 iterations back was interior (issued all its stores)
+#ifdef WS_STAMP
+    unsigned long long st_wait = 0, st_bar = 0, st_main = 0, st_epi = 0, st_n = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (; cc.tile < total_tiles; advance(cc)) {
+#ifdef WS_STAMP
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
         // Counted wait for this tile's pieces.  VMEM ops retire in issue order; per wave the ops younger than
         // P(tile k) are: S(k-2), P(k+1), S(k-1).  The count is exact only when both previous tiles were interior
         // (every predicated store really issued); otherwise, and for the first two tiles, drain.
@@ -1198,8 +1216,14 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NAW + DIST * NST) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WS_STAMP
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef WS_STAMP
+        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+#endif
         const bool more = cn.tile < total_tiles;
         unsigned char* nbase = smem + ((cur + DIST) % NBUF) * A_BYTES;
         const int ny0 = cn.ty * G::THS, nx0 = cn.tx * TW, nimg = cn.img;
@@ -1236,6 +1260,9 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
             __builtin_amdgcn_sched_barrier(0);
         }
         static_assert((NAW - 1) * PSTEP < NQ, "all pieces issued inside the step walk");
+#ifdef WS_STAMP
+        const unsigned long long td = __builtin_amdgcn_s_memtime();
+#endif
         advance(cn);
         if (MT == 1) {
 #pragma unroll
@@ -1251,48 +1278,73 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
             hist = 0;
             continue;
         }
+        // Software-pipelined over the 2 * MT half sub-tiles (16 pixels x 32 channels each) on TWO scratch tiles: the
+        // read-back of half k is issued, then half k + 1 is converted and written to the other tile, and only then half
+        // k's 16-byte store consumes the read -- the LDS round trip (several hundred cycles while the other workgroup's
+        // fragment reads keep the LDS busy: round-4 stamps put the epilogue at 3410 cycles per tile, as long as the MFMA
+        // loop, four dependent round trips) runs under the next half's conversions instead of in front of them.
+        bf16x8 pend = {};
+        int pend_rel = 0;
+        bool pend_ok = false;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int idx = 0; idx < 2 * MT; ++idx) {
+            const int i = idx >> 1, half = idx & 1;
             const int yr = 2 * (wm * MT + i);  // first of the sub-tile's two tile rows
+            unsigned char* const sc = scr + (idx & 1) * 1024;
+            if (interior) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (interior) {
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
+                    const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
+                    reinterpret_cast<bf16*>(sc)[(rr & 15) * 32 + r] = (bf16)v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            } else {
 #pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) {
-                        const int e = half * 8 + e8;
-                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // rr >> 4 == half
-                        const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
-                        reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
+                    reinterpret_cast<bf16*>(sc)[(rr & 15) * 32 + r] = (bf16)v;
+                    if (y0 + yr + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
                         ssum += v;
                         ssq += v * v;
                     }
-                } else {
-#pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) {
-                        const int e = half * 8 + e8;
-                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = aff ? fmaxf(fmaf(acc[i][e], scl, bv), 0.f) : acc[i][e] + bv;
-                        reinterpret_cast<bf16*>(scr)[(rr & 15) * 32 + r] = (bf16)v;
-                        if (y0 + yr + half < p.H && x0 + sub_px<MODE>(rr) < p.W) {
-                            ssum += v;
-                            ssq += v * v;
-                        }
-                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                {
-                    const bf16x8 o = *reinterpret_cast<const bf16x8*>(scr + (s_px * 32 + (lane & 3) * 8) * 2);
-                    const int rel = (yr + half) * p.W + s_x[half];
-                    if (interior || (y0 + yr + half < p.H && x0 + s_x[half] < p.W && !(DBG && (p.debug & 16))))
-                        *reinterpret_cast<bf16x8*>(s_dst + (long)(tbase + rel) * s_stride) = o;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (idx > 0 && pend_ok) *reinterpret_cast<bf16x8*>(s_dst + (long)(tbase + pend_rel) * s_stride) = pend;
+            pend = *reinterpret_cast<const bf16x8*>(sc + (s_px * 32 + (lane & 3) * 8) * 2);
+            pend_rel = (yr + half) * p.W + s_x[half];
+            pend_ok = interior || (y0 + yr + half < p.H && x0 + s_x[half] < p.W && !(DBG && (p.debug & 16)));
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        if (pend_ok) *reinterpret_cast<bf16x8*>(s_dst + (long)(tbase + pend_rel) * s_stride) = pend;
         hist = ((hist << 1) | (interior ? 1 : 0)) & 3;
+#ifdef WS_STAMP
+        {
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            st_wait += tb - ta;
+            st_bar += tc - tb;
+            st_main += td - tc;
+            st_epi += te - td;
+            st_n += 1;
+        }
+#endif
     }
+#ifdef WS_STAMP
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_ws_stamp + blockIdx.x * 8;
+        o[0] = st_wait; o[1] = st_bar; o[2] = st_main; o[3] = st_epi; o[4] = st_n;
+        o[5] = __builtin_amdgcn_s_memtime() - st_t0;
+        o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        o[7] = st_r0;
+    }
+#endif
     if (p.stats) {
         const float S = ssum + __shfl_xor(ssum, 32, 64);
         const float Q = ssq + __shfl_xor(ssq, 32, 64);
