@@ -32,10 +32,41 @@ static int conv_bn_relu(const hipseg_convblock_t* a, const void* in0, int c0, co
     return hipseg_bn_relu_apply(dt, raw, scale, shift, act, B, H, W, C, pool, s);
 }
 
+// BatchNorm + ReLU of the first layer applied in the second convolution's load path (and in its weight gradient's):
+// train mode, both kernels with the load-side transform take the shape, and the paired weight gradient (which reads the
+// activated tensor for its second problem) does not.  Decided from shapes only: forward and backward agree.
+static bool bn_on_load(const hipseg_convblock_t* a) {
+    const int C = a->Cout;
+    return a->train && hipseg_conv3_bnrelu_in_applies(a->dtype, C, C, a->B, a->H, a->W) &&
+           hipseg_conv_wgrad_bnrelu_p_applies(a->dtype, C, C, a->B, a->H, a->W) &&
+           !hipseg_conv_wgrad_pair_applies(a->dtype, a->C0, a->C1, C, C, a->B, a->H, a->W);
+}
+
 extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stream_t s) {
     HS_REQUIRE(a && a->x0 && a->wp1 && a->wp2 && a->raw1 && a->a1 && a->raw2 && a->out && a->bn1 && a->bn2,
                "convblock_forward: null operand");
     HS_REQUIRE(!a->train || a->stats, "convblock_forward: train mode needs the statistics workspace");
+    if (bn_on_load(a)) {
+        // conv -> statistics -> (scale, shift); the activated intermediate a1 is NOT written: the second convolution
+        // transforms raw1 on load
+        const int C = a->Cout, B = a->B, H = a->H, W = a->W, dt = a->dtype;
+        float *bn1 = a->bn1, *bn2 = a->bn2;
+        if (int rc = hipseg_conv_igemm(dt, HIPSEG_CONV3, a->x0, a->C0, a->x1, a->C1, a->wp1, a->b1, a->raw1, C, nullptr, 0,
+                                       a->stats, B, H, W, s))
+            return rc;
+        if (int rc = hipseg_bn_finalize(a->stats, hipseg_conv_stats_rows(dt, HIPSEG_CONV3, a->C0, a->C1, C, 0, B, H, W), C,
+                                        (double)B * H * W, a->g1, a->be1, a->eps, a->momentum, a->rm1, a->rv1, a->nbt1, bn1,
+                                        bn1 + C, bn1 + 2 * (size_t)C, bn1 + 3 * (size_t)C, s))
+            return rc;
+        if (int rc = hipseg_conv3_bnrelu_in(dt, a->raw1, C, bn1 + 2 * (size_t)C, bn1 + 3 * (size_t)C, a->wp2, a->b2, a->raw2, C,
+                                            a->stats, B, H, W, s))
+            return rc;
+        if (int rc = hipseg_bn_finalize(a->stats, hipseg_conv_stats_rows(dt, HIPSEG_CONV3, C, 0, C, 0, B, H, W), C,
+                                        (double)B * H * W, a->g2, a->be2, a->eps, a->momentum, a->rm2, a->rv2, a->nbt2, bn2,
+                                        bn2 + C, bn2 + 2 * (size_t)C, bn2 + 3 * (size_t)C, s))
+            return rc;
+        return hipseg_bn_relu_apply(dt, a->raw2, bn2 + 2 * (size_t)C, bn2 + 3 * (size_t)C, a->out, B, H, W, C, a->pool, s);
+    }
     if (int rc = conv_bn_relu(a, a->x0, a->C0, a->x1, a->C1, a->wp1, a->b1, a->g1, a->be1, a->rm1, a->rv1, a->nbt1, a->raw1,
                               a->a1, a->bn1, 0, s))
         return rc;
@@ -74,7 +105,11 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
     const bool pair = a->draw1 != a->draw2 && hipseg_conv_wgrad_pair_applies(dt, a->C0, a->C1, C, C, B, H, W);
     // second conv layer
     if (int rc = bn_relu_bwd(a, a->dout, a->dout2, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
-    if (!pair)
+    if (bn_on_load(a)) {  // (a1 was never written: the weight gradient transforms raw1 on load)
+        if (int rc = hipseg_conv_wgrad_bnrelu_p(dt, a->raw1, C, a->bn1 + 2 * (size_t)C, a->bn1 + 3 * (size_t)C, a->draw2, C,
+                                                a->dw2, a->slabs, B, H, W, s))
+            return rc;
+    } else if (!pair)
         if (int rc = hipseg_conv_wgrad(dt, HIPSEG_CONV3, a->a1, C, nullptr, 0, a->draw2, C, a->dw2, a->slabs, B, H, W, s))
             return rc;
     // data gradient of the second conv; where a kernel with that epilogue takes the shape it also reduces the

@@ -17,6 +17,10 @@ struct ConvArgs {
     // writes [sum g | sum g * xhat] rows of the output into `stats`.  NULL = off.
     const void* bw_x;
     const float* bw_bn;
+    // BatchNorm + ReLU applied on LOAD (hipseg_conv3_bnrelu_in, weights-stationary kernel only): the convolution runs
+    // over relu(in0 * ld_scale[c] + ld_shift[c]), zero-padded.  NULL = off.
+    const float* ld_scale;
+    const float* ld_shift;
     int C0, C1, N0, N1;
     int B, H, W;    // GEMM-M pixel grid
     int Hi, Wi;     // input spatial dims

@@ -1080,7 +1080,14 @@ extern "C" int hipseg_debug_ws_stamps(void* host, int nwg) {
 namespace {
 #endif
 
-template <int KCH, int NB, bool DBG, bool AFF = false>
+// LD (round 4, hipseg_conv3_bnrelu_in): the INPUT tensor is the pre-normalisation output of the previous convolution and
+// the convolution runs over relu(in * ld_scale[c] + ld_shift[c]) -- BatchNorm + ReLU applied in the consumer's load path
+// (SURVEY section 2.2), so the activated tensor and the bn_relu_apply pass that wrote it never exist.  The wave that
+// DMA'd a piece rewrites it in LDS after its own counted wait and before the tile's barrier (its 8 channels are one
+// octet: scale / shift are wave-uniform scalars); lanes whose pixel lies outside the image keep the zero the DMA
+// filled in (the convolution pads the ACTIVATED tensor with zeros).  Measured cost on 64 -> 64 at 256 x 256: +7 us on
+// an 82-us launch (profiles/r04_bn_on_load.txt) against the 40-57 us pass it removes.
+template <int KCH, int NB, bool DBG, bool AFF = false, bool LD = false>
 __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int total_tiles, int tiles_y8) {
     typedef bf16 T;
     typedef WsGeo<KCH, NB> G;
@@ -1219,6 +1226,40 @@ __global__ __launch_bounds__(256, 2) void conv3_wstat_kernel(ConvArgs p, int tot
 #ifdef WS_STAMP
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (LD) {
+            // scale / shift of an octet are wave-uniform: re-read per tile through scalar loads (scalar-cache hits, one
+            // wait per octet) instead of living in registers across the tile loop -- the kernel has none to spare (32
+            // more values spilled 26 VGPRs to scratch; one scalar load per PIECE with its own wait cost 55 us)
+            unsigned char* sAw = smem + cur * A_BYTES;
+            const int ly0 = cc.ty * G::THS - 1, lx0 = cc.tx * TW - 1;
+#pragma unroll
+            for (int o = 0; o < OPW; ++o) {
+                const int oct = __builtin_amdgcn_readfirstlane(wave * OPW + o);
+                // (constant address space: SCALAR loads -- as vector loads they would count in vmcnt and the compiler's wait
+                // for them would drain the LDS-DMA pieces of the next tiles and the previous tile's stores: 137 us)
+                typedef const __attribute__((address_space(4))) float cfloat;
+                cfloat* sp = (cfloat*)(p.ld_scale + oct * 8);
+                cfloat* hp = (cfloat*)(p.ld_shift + oct * 8);
+                float sc[8], sh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sc[e] = sp[e];
+                    sh[e] = hp[e];
+                }
+                bf16x8 v[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) v[g] = *(reinterpret_cast<bf16x8*>(sAw + (oct * NG + g) * 1024) + lane);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int gy = ly0 + (pyx[g] & 0xff), gx = lx0 + (pyx[g] >> 8);
+                    const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[g][e] = (bf16)(in ? fmaxf((float)v[g][e] * sc[e] + sh[e], 0.f) : 0.f);
+                    *(reinterpret_cast<bf16x8*>(sAw + (oct * NG + g) * 1024) + lane) = v[g];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #ifdef WS_STAMP
@@ -1365,7 +1406,12 @@ int launch_wstat(const ConvArgs& a, hipStream_t s) {
     const int tiles_y8 = cdiv(a.H, G::THS);
     const long total = (long)a.B * a.tiles_x * tiles_y8;
     const long grid = 2 * a.ncu;  // wstat_grid(): total >= 4 * ncu
-    if (a.post_scale) {
+    if (a.ld_scale) {
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false, false, true>), (size_t)G::LDS))
+            return rc;
+        hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, false, false, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a,
+                           (int)total, tiles_y8);
+    } else if (a.post_scale) {
         if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&conv3_wstat_kernel<KCH, NB, false, true>), (size_t)G::LDS))
             return rc;
         hipLaunchKernelGGL((conv3_wstat_kernel<KCH, NB, false, true>), dim3((unsigned)grid), dim3(256), G::LDS, s, a,
@@ -1537,7 +1583,7 @@ extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N
 static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const void* in1, int C1, const void* wp,
                            const float* bias, const float* post_scale, void* out0, int N0, void* out1, int N1,
                            float* stats, int B, int H, int W, hipseg_stream_t stream, const void* bw_x = nullptr,
-                           const float* bw_bn = nullptr) {
+                           const float* bw_bn = nullptr, const float* ld_scale = nullptr, const float* ld_shift = nullptr) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_igemm: bad dtype %d", dtype);
     HS_REQUIRE(mode >= HIPSEG_CONV3 && mode <= HIPSEG_CONVT, "conv_igemm: bad mode %d", mode);
     HS_REQUIRE(in0 && wp && out0 && C0 > 0 && N0 > 0, "conv_igemm: null operand or empty channel range");
@@ -1556,6 +1602,8 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
     a.stats = stats;
     a.bw_x = bw_x;
     a.bw_bn = bw_bn;
+    a.ld_scale = ld_scale;
+    a.ld_shift = ld_shift;
     a.C0 = C0;
     a.C1 = C1;
     a.N0 = N0;
@@ -1592,6 +1640,7 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
             if (a.Kp == 64) return a.Np == 64 ? launch_wstat<4, 2>(a, s) : launch_wstat<4, 1>(a, s);
             return a.Np == 64 ? launch_wstat<2, 2>(a, s) : launch_wstat<2, 1>(a, s);
         }
+        HS_REQUIRE(!ld_scale, "conv3_bnrelu_in: no kernel with the load-side BatchNorm takes this shape");
         // the ring kernel addresses its operands through buffer descriptors with 2^30 / 2^31 out-of-range markers
         const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
@@ -1674,6 +1723,26 @@ extern "C" int hipseg_conv3_dgrad_bnstats(int dtype, const void* dy, int C, cons
                "conv3_dgrad_bnstats: unsupported shape (ask hipseg_conv3_dgrad_bnstats_rows first)");
     return conv_igemm_impl(dtype, HIPSEG_CONV3, dy, C, nullptr, 0, wp, nullptr, nullptr, out, N, nullptr, 0, partial, B, H, W,
                            stream, x, bn);
+}
+
+// conv3x3 over relu(in * scale[c] + shift[c]) (zero-padded): the BatchNorm + ReLU of the PREVIOUS layer applied in this
+// convolution's load path, so that layer's activated tensor is never written or read (the second
+// convolution of a ConvBlock at the full-resolution levels, /root/reference/models/processing_blocks.py:44-46).  Same
+// arithmetic as hipseg_bn_relu_apply followed by hipseg_conv_igemm: bit-identical results.
+extern "C" int hipseg_conv3_bnrelu_in_applies(int dtype, int C, int N, int B, int H, int W) {
+    static const bool off = getenv("HIPSEG_NO_BN_ON_LOAD") != nullptr;  // A/B switch
+    if (off || (C != 64 && C != 32)) return 0;
+    return wstat_grid(dtype, HIPSEG_CONV3, C, 0, N, 0, B, H, W) ? 1 : 0;
+}
+
+extern "C" int hipseg_conv3_bnrelu_in(int dtype, const void* in, int C, const float* scale, const float* shift, const void* wp,
+                                      const float* bias, void* out, int N, float* stats, int B, int H, int W,
+                                      hipseg_stream_t stream) {
+    HS_REQUIRE(scale && shift, "conv3_bnrelu_in: scale and shift are required");
+    HS_REQUIRE(hipseg_conv3_bnrelu_in_applies(dtype, C, N, B, H, W),
+               "conv3_bnrelu_in: unsupported shape (ask hipseg_conv3_bnrelu_in_applies first)");
+    return conv_igemm_impl(dtype, HIPSEG_CONV3, in, C, nullptr, 0, wp, bias, nullptr, out, N, nullptr, 0, stats, B, H, W, stream,
+                           nullptr, nullptr, scale, shift);
 }
 
 // Inference form of conv3x3 -> BatchNorm(running statistics) -> ReLU in ONE kernel: the per-channel affine is applied to

@@ -55,6 +55,10 @@ struct WgArgs {
     int convt_cout;
     int debug;  // ablation bits (HIPSEG_WGRAD_DEBUG): 1 skip P staging, 2 skip Q staging, 4 skip MFMA, 8 skip slab store
     int xcd;    // XCD-aware workgroup order: 0 off, else grid / 8 (see xcd_block)
+    // BatchNorm + ReLU applied to P on LOAD (hipseg_conv_wgrad_bnrelu_p): P holds the pre-normalisation tensor and the
+    // gradient is taken against relu(P * p_scale[u] + p_shift[u]) (zero-padded).  NULL = off.
+    const float* p_scale;
+    const float* p_shift;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Give every XCD a CONTIGUOUS run of
@@ -558,7 +562,11 @@ struct Tr16Geo {
 // and a lane whose pixel lies beyond the image's bottom / right edge does not fetch (zero fill: it contributes nothing):
 // its halo coordinates are two more per-lane constants per piece, compared with two per-tile limits.  A separate
 // instantiation, so the whole-tile kernels of the U-Nets keep their 3-instruction pieces.
-template <bool PAIR, bool RAGGED = false>
+// ONLOAD (round 4): see WgArgs::p_scale -- the wave that DMA'd a P piece rewrites it in LDS as relu(x * scale + shift)
+// after its wait and before the tile's barrier; lanes whose halo pixel lies outside the image keep the DMA's zero.  The
+// weight gradient of a convolution whose input exists only pre-BatchNorm (the second convolution of a full-resolution
+// ConvBlock when the forward applied BatchNorm + ReLU on load, hipseg_conv3_bnrelu_in).  Whole tiles, single launch.
+template <bool PAIR, bool RAGGED = false, bool ONLOAD = false>
 __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2, int tA, int tB) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef Tr16Geo G;
@@ -613,6 +621,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
     // lane -> (pixel row of the piece, 16-byte slot); source slot = destination slot with its 32-byte index XOR-ed
     const int prow = lane >> 3, slot = lane & 7;
     const unsigned colsrc = (unsigned)((((slot >> 1) ^ ((prow >> 1) & 3)) << 1) | (slot & 1)) * 16u;
+    float psc[ONLOAD ? 8 : 1], psh[ONLOAD ? 8 : 1];  // ONLOAD: scale / shift of the 8 channels this lane copies
+    if constexpr (ONLOAD) {
+        const int c0 = u0 + (int)(colsrc >> 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            psc[e] = a.p_scale[c0 + e];
+            psh[e] = a.p_shift[c0 + e];
+        }
+    }
     // 5 flags per P piece: halo pixel in the top / bottom halo row, left / right halo column, lane beyond the halo tile
     unsigned pofs[NPW_P], qofs[NPW_Q], pflags = 0;
     unsigned pyx[RAGGED ? NPW_P : 1];  // RAGGED: halo row | halo column << 8 of the lane's pixel of piece j
@@ -704,8 +721,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // prologue: the first tile
+    unsigned cur_edge = 16u;  // ONLOAD: edge mask of the tile being computed (staged one iteration earlier)
     if (ntile < a.ntiles) {
         const TileS t0 = tile_scalars(nimg, nty * G::TH, ntx * TW);
+        cur_edge = t0.edge;
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) piece(j, lds0, t0);
     }
@@ -723,6 +742,20 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
 #ifdef WG_STAMP
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (ONLOAD) {
+#pragma unroll
+            for (int j = 0; j < NPW_P; ++j) {
+                const int pc = j * NW + wave;
+                if ((j + 1) * NW <= NPC_P || pc < NPC_P) {  // wave-uniform
+                    bf16x8* q = reinterpret_cast<bf16x8*>(smem + cur * BUF + pc * 1024) + lane;
+                    bf16x8 v = *q;
+                    const bool in = !(pflags & (cur_edge << (5 * j)));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)(in ? fmaxf((float)v[e] * psc[e] + psh[e], 0.f) : 0.f);
+                    *q = v;
+                }
+            }
+        }
         __builtin_amdgcn_s_barrier();                      // everyone's have; everyone left the other slot
         __builtin_amdgcn_sched_barrier(0);
 #ifdef WG_STAMP
@@ -802,6 +835,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
         }
 #endif
         advance();
+        cur_edge = tn.edge;
         {  // fragment bases follow the ring slot (in place: no second set of address registers)
             const unsigned d = cur ? (unsigned)-BUF : (unsigned)BUF;
 #pragma unroll
@@ -856,7 +890,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr16_kernel(WgArgs a, WgArgs b2
 
 int launch_tr16(const WgArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.S * a.UT * a.VT));
-    if (a.H % 16 || a.W % 16) {
+    if (a.p_scale) {  // (whole tiles, single source: checked by hipseg_conv_wgrad_bnrelu_p_applies)
+        if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false, false, true>), (size_t)Tr16Geo::LDS))
+            return rc;
+        hipLaunchKernelGGL((wgrad3_tr16_kernel<false, false, true>), grid, dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
+    } else if (a.H % 16 || a.W % 16) {
         if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&wgrad3_tr16_kernel<false, true>), (size_t)Tr16Geo::LDS)) return rc;
         hipLaunchKernelGGL((wgrad3_tr16_kernel<false, true>), grid, dim3(512), Tr16Geo::LDS, s, a, a, 0, 0);
     } else {
@@ -1027,9 +1065,39 @@ extern "C" size_t hipseg_wgrad_workspace_elems(int mode, int CU, int CV, int B, 
     return m;
 }
 
+static int conv_wgrad_impl(int dtype, int mode, const void* p0, int CU0, const void* p1, int CU1, const void* q, int CV,
+                           float* dw, float* slabs, int B, int H, int W, hipseg_stream_t stream, const float* p_scale,
+                           const float* p_shift);
+
 extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, const void* p1, int CU1,
                                  const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
                                  hipseg_stream_t stream) {
+    return conv_wgrad_impl(dtype, mode, p0, CU0, p1, CU1, q, CV, dw, slabs, B, H, W, stream, nullptr, nullptr);
+}
+
+// 3x3 weight gradient against relu(P * scale[u] + shift[u]) with P the PRE-normalisation tensor (BatchNorm + ReLU of the
+// previous layer applied in the load path, the counterpart of hipseg_conv3_bnrelu_in in backward): the second
+// convolution of a ConvBlock whose activated intermediate was never written.  bf16, >= 64 channels in multiples of 64 on
+// both sides, whole 16 x 16 tiles (the tr16 kernel's single-launch form).
+extern "C" int hipseg_conv_wgrad_bnrelu_p_applies(int dtype, int CU, int CV, int B, int H, int W) {
+    static const bool off = getenv("HIPSEG_NO_BN_ON_LOAD") != nullptr || getenv("HIPSEG_NO_WGRAD_TR16") != nullptr ||
+                            getenv("HIPSEG_NO_DMA") != nullptr;
+    if (off || dtype != HIPSEG_BF16 || CU % 64 || CV % 64 || H % 16 || W % 16) return 0;
+    return (size_t)B * H * W * (size_t)(CU > CV ? CU : CV) * 2 <= ((size_t)1 << 30) ? 1 : 0;
+}
+
+extern "C" int hipseg_conv_wgrad_bnrelu_p(int dtype, const void* p, int CU, const float* scale, const float* shift,
+                                          const void* q, int CV, float* dw, float* slabs, int B, int H, int W,
+                                          hipseg_stream_t stream) {
+    HS_REQUIRE(scale && shift, "conv_wgrad_bnrelu_p: scale and shift are required");
+    HS_REQUIRE(hipseg_conv_wgrad_bnrelu_p_applies(dtype, CU, CV, B, H, W),
+               "conv_wgrad_bnrelu_p: unsupported shape (ask hipseg_conv_wgrad_bnrelu_p_applies first)");
+    return conv_wgrad_impl(dtype, HIPSEG_CONV3, p, CU, nullptr, 0, q, CV, dw, slabs, B, H, W, stream, scale, shift);
+}
+
+static int conv_wgrad_impl(int dtype, int mode, const void* p0, int CU0, const void* p1, int CU1, const void* q, int CV,
+                           float* dw, float* slabs, int B, int H, int W, hipseg_stream_t stream, const float* p_scale,
+                           const float* p_shift) {
     HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "conv_wgrad: bad dtype %d", dtype);
     HS_REQUIRE(mode == HIPSEG_CONV3 || mode == HIPSEG_CONV1 || mode == HIPSEG_CONVT, "conv_wgrad: bad mode %d", mode);
     HS_REQUIRE(p0 && q && dw && slabs && CU0 > 0 && CV > 0, "conv_wgrad: null operand or empty channel range");
@@ -1078,6 +1146,8 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
     a.vec_ok_p = (CU0 % vec == 0) && (CU1 % vec == 0);
     a.vec_ok_q = (CV % vec == 0);
     a.convt_cout = mode == HIPSEG_CONVT ? CU0 : 0;
+    a.p_scale = p_scale;
+    a.p_shift = p_shift;
 #ifdef HIPSEG_ABLATE  // ablation bits give wrong results by design: ablation builds only (scripts/build_variant.sh)
     static const int dbg = getenv("HIPSEG_WGRAD_DEBUG") ? atoi(getenv("HIPSEG_WGRAD_DEBUG")) : 0;
 #else
@@ -1098,6 +1168,7 @@ extern "C" int hipseg_conv_wgrad(int dtype, int mode, const void* p0, int CU0, c
                           ((H % 16 == 0 && W % 16 == 0) || !no_ragged) &&
                           (CU1 == 0 || CU0 % 64 == 0) &&
                           (size_t)B * H * W * (size_t)(CU0 > CV ? (CU0 > CU1 ? CU0 : CU1) : (CV > CU1 ? CV : CU1)) * 2 <= ((size_t)1 << 30);
+        HS_REQUIRE(tr16 || !p_scale, "conv_wgrad_bnrelu_p: the shape does not take the kernel with the load-side BatchNorm");
         if (tr16)
             rc = launch_tr16(a, s);
         else if (dma)
@@ -1213,6 +1284,8 @@ WgArgs tr16_args(const void* p0, int CU0, const void* p1, int CU1, const void* q
     a.vec_ok_p = 1;
     a.vec_ok_q = 1;
     a.convt_cout = 0;
+    a.p_scale = nullptr;
+    a.p_shift = nullptr;
     a.debug = 0;
     a.xcd = 0;
     return a;

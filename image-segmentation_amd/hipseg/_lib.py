@@ -45,6 +45,10 @@ PROTOTYPES = {
     "hipseg_event_record_external": (I, [P, P]),
     "hipseg_stream_wait_event": (I, [P, P]),
     "hipseg_conv_affine_relu": (I, [I, P, I, P, I, P, P, P, P, I, I, I, I, P]),
+    "hipseg_conv3_bnrelu_in_applies": (I, [I, I, I, I, I, I]),
+    "hipseg_conv3_bnrelu_in": (I, [I, P, I, P, P, P, P, P, I, P, I, I, I, P]),
+    "hipseg_conv_wgrad_bnrelu_p_applies": (I, [I, I, I, I, I, I]),
+    "hipseg_conv_wgrad_bnrelu_p": (I, [I, P, I, P, P, P, I, P, P, I, I, I, P]),
     "hipseg_conv3_dgrad_bnstats_rows": (I, [I, I, I, I, I, I]),
     "hipseg_conv3_dgrad_bnstats": (I, [I, P, I, P, P, I, P, P, P, I, I, I, P]),
     "hipseg_wgrad_workspace_elems": (c_size_t, [I, I, I, I, I, I]),
@@ -105,7 +109,8 @@ class ConvBlockArgs(ctypes.Structure):
                                             "db1", "db2", "sums1", "sums2", "partial", "slabs", "colpart")])
 
 # functions whose int return value is a geometry answer, not a status code
-_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_bn_bwd_blocks",
+_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_conv3_bnrelu_in_applies",
+         "hipseg_conv_wgrad_bnrelu_p_applies", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
          "hipseg_wgrad_workspace_elems", "hipseg_convT_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size",
          "hipseg_convblock_size"}

@@ -124,6 +124,29 @@ int hipseg_conv_affine_relu(int dtype, const void* in0, int C0, const void* in1,
                             const float* scale, const float* shift, void* out, int N, int B, int H, int W,
                             hipseg_stream_t stream);
 
+/* ---- BatchNorm + ReLU applied in the CONSUMER's load path (round 4) ------------------------------
+ * The second convolution of a ConvBlock reads relu(bn(raw1)); at the full-resolution levels (<= 64 channels) writing that
+ * activated tensor and reading it back (hipseg_bn_relu_apply: 2 x 134 MB at 64 channels x 16 x 256 x 256) costs more
+ * than transforming the pre-normalisation tensor on its way into the kernels that consume it:
+ *   hipseg_conv3_bnrelu_in     : out = conv3x3(relu(in * scale[c] + shift[c]), zero-padded) (+ bias, + statistics rows as
+ *                                hipseg_conv_igemm); the wave that LDS-DMA'd a piece of the halo tile rewrites it in LDS.
+ *   hipseg_conv_wgrad_bnrelu_p : the 3x3 weight gradient against relu(p * scale[u] + shift[u]) (P operand rewritten in
+ *                                LDS the same way), dw (CV, CU, 3, 3).
+ * Same arithmetic as apply-then-consume: results are bit-identical to hipseg_bn_relu_apply followed by
+ * hipseg_conv_igemm / hipseg_conv_wgrad.  *_applies: 1 when the shape has a kernel with the load-side transform (bf16;
+ * conv: 32 or 64 input channels, 32 / 64 output channels, >= 4 x CUs tiles of 8 x 16 pixels; weight gradient: channel
+ * counts multiples of 64, H and W multiples of 16).  hipseg_convblock_forward / _backward take this path on their own
+ * when both apply to the block's second convolution and the paired weight gradient does not (then `a1` is not written).
+ * replaces: aten::native_batch_norm + aten::relu_ materialising the intermediate of
+ *           models/processing_blocks.py:44-46 (and its re-read by cuDNN's backward-filter). */
+int hipseg_conv3_bnrelu_in_applies(int dtype, int C, int N, int B, int H, int W);
+int hipseg_conv3_bnrelu_in(int dtype, const void* in, int C, const float* scale, const float* shift, const void* wp,
+                           const float* bias, void* out, int N, float* stats, int B, int H, int W,
+                           hipseg_stream_t stream);
+int hipseg_conv_wgrad_bnrelu_p_applies(int dtype, int CU, int CV, int B, int H, int W);
+int hipseg_conv_wgrad_bnrelu_p(int dtype, const void* p, int CU, const float* scale, const float* shift, const void* q,
+                               int CV, float* dw, float* slabs, int B, int H, int W, hipseg_stream_t stream);
+
 /* ---- data gradient + BatchNorm-backward sums in one kernel ----------------------------------------
  * hipseg_conv3_dgrad_bnstats: out = the data gradient hipseg_conv_igemm(HIPSEG_CONV3, in0 = dy, wp = data-gradient
  * operand) computes, for a convolution whose INPUT was relu(bn(x)); in the same kernel the BatchNorm-backward sums

@@ -215,3 +215,86 @@ def test_convT_weight_and_bias_gradient_in_one_kernel(hs, case):
     sw, sb = float(w.grad.abs().max()), float(b.grad.abs().max())
     assert (dw.double() - w.grad).abs().max() <= 2e-5 * max(1.0, sw) * (B * H * W) ** 0.5
     assert (db.double() - b.grad).abs().max() <= 2e-5 * max(1.0, sb) * (B * H * W) ** 0.5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 256, 256), (4, 32, 32, 128, 256), (2, 64, 32, 256, 256), (3, 32, 64, 200, 232)],
+                         ids=str)
+def test_conv_with_batchnorm_relu_on_load_is_bit_identical(hs, case):
+    """hipseg_conv3_bnrelu_in == hipseg_bn_relu_apply followed by hipseg_conv_igemm, bit for bit (output and statistics
+    rows), incl. ragged image borders: the zero padding is of the ACTIVATED tensor (relu(shift) must not leak in)."""
+    L, ops = hs.L, hs.ops
+    B, C, N, H, W = case
+    td, dt = torch.bfloat16, L.BF16
+    assert L.conv3_bnrelu_in_applies(dt, C, N, B, H, W)
+    raw = to_dev_nhwc(rnd(T("r4.ol.raw", (B, C, H, W), -2, 2), td), td)
+    scale = T("r4.ol.sc", (C,), -1.5, 1.5).cuda()
+    shift = T("r4.ol.sh", (C,), 0.2, 0.9).cuda()  # positive shifts: relu(shift) != 0 would show at the borders
+    w = T("r4.ol.w", (N, C, 3, 3), -0.3, 0.3).cuda()
+    bias = T("r4.ol.b", (N,), -0.5, 0.5).cuda()
+    wp = ops._pack_conv(w, dt, False)
+    s = ops._stream()
+    act = ops.nhwc_empty(B, C, H, W, td, "cuda")
+    L.bn_relu_apply(dt, ops.ptr(raw), ops.ptr(scale), ops.ptr(shift), ops.ptr(act), B, H, W, C, 0, s)
+    mt = L.conv_mtiles(B, H, W)
+    rows = L.conv_stats_rows(dt, L.CONV3, C, 0, N, 0, B, H, W)
+    ref, st_ref = ops.nhwc_empty(B, N, H, W, td, "cuda"), torch.zeros(mt, 2, N, device="cuda")
+    L.conv_igemm(dt, L.CONV3, ops.ptr(act), C, 0, 0, ops.ptr(wp), ops.ptr(bias), ops.ptr(ref), N, 0, 0, ops.ptr(st_ref), B, H, W, s)
+    out, st = ops.nhwc_empty(B, N, H, W, td, "cuda"), torch.zeros(mt, 2, N, device="cuda")
+    L.conv3_bnrelu_in(dt, ops.ptr(raw), C, ops.ptr(scale), ops.ptr(shift), ops.ptr(wp), ops.ptr(bias), ops.ptr(out), N, ops.ptr(st),
+                      B, H, W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(st[:rows], st_ref[:rows])
+    assert float(out.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (1, 128, 64, 32, 48), (16, 64, 64, 128, 128)], ids=str)
+def test_wgrad_with_batchnorm_relu_on_load_is_bit_identical(hs, case):
+    """hipseg_conv_wgrad_bnrelu_p == hipseg_bn_relu_apply followed by hipseg_conv_wgrad, bit for bit."""
+    L, ops = hs.L, hs.ops
+    B, CU, CV, H, W = case
+    td, dt = torch.bfloat16, L.BF16
+    assert L.conv_wgrad_bnrelu_p_applies(dt, CU, CV, B, H, W)
+    raw = to_dev_nhwc(rnd(T("r4.ow.raw", (B, CU, H, W), -2, 2), td), td)
+    dy = to_dev_nhwc(rnd(T("r4.ow.dy", (B, CV, H, W)), td), td)
+    scale = T("r4.ow.sc", (CU,), -1.5, 1.5).cuda()
+    shift = T("r4.ow.sh", (CU,), 0.2, 0.9).cuda()
+    s = ops._stream()
+    act = ops.nhwc_empty(B, CU, H, W, td, "cuda")
+    L.bn_relu_apply(dt, ops.ptr(raw), ops.ptr(scale), ops.ptr(shift), ops.ptr(act), B, H, W, CU, 0, s)
+    slabs = torch.empty(L.wgrad_workspace_elems(L.CONV3, CU, CV, B, H, W), device="cuda")
+    ref = torch.full((CV, CU, 3, 3), float("nan"), device="cuda")
+    L.conv_wgrad(dt, L.CONV3, ops.ptr(act), CU, 0, 0, ops.ptr(dy), CV, ops.ptr(ref), ops.ptr(slabs), B, H, W, s)
+    got = torch.full((CV, CU, 3, 3), float("nan"), device="cuda")
+    L.conv_wgrad_bnrelu_p(dt, ops.ptr(raw), CU, ops.ptr(scale), ops.ptr(shift), ops.ptr(dy), CV, ops.ptr(got), ops.ptr(slabs), B, H,
+                          W, s)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and bool(torch.isfinite(got).all())
+
+
+def test_convblock_with_batchnorm_on_load_equals_per_op_path(hs):
+    """a full-resolution ConvBlockDownsample (32 -> 64 at 2 x 256 x 256: the block call applies the first BatchNorm + ReLU in
+    the second convolution's load path and never writes the intermediate) against the per-op path, which materialises it:
+    outputs, input gradient, every parameter gradient and the BatchNorm buffers bit for bit."""
+    from models.processing_blocks import ConvBlockDownsample
+
+    L, ops = hs.L, hs.ops
+    assert L.conv3_bnrelu_in_applies(L.BF16, 64, 64, 2, 256, 256) and L.conv_wgrad_bnrelu_p_applies(L.BF16, 64, 64, 2, 256, 256)
+    assert not L.conv_wgrad_pair_applies(L.BF16, 32, 0, 64, 64, 2, 256, 256)
+    res = []
+    for per_op in (False, True):
+        torch.manual_seed(7)
+        m = ConvBlockDownsample(32, 64).cuda().train()
+        x = to_dev_nhwc(T("r4.blkol", (2, 32, 256, 256)), torch.bfloat16).requires_grad_(True)
+        old = ops._NO_BLOCK_CALLS
+        ops._NO_BLOCK_CALLS = per_op
+        try:
+            with torch.autocast("cuda"):
+                y = m(x)
+            y.float().square().mean().backward()
+        finally:
+            ops._NO_BLOCK_CALLS = old
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad] + [p.grad.clone() for p in m.parameters()] + [b.clone() for b in m.buffers()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
