@@ -237,9 +237,9 @@ def _config_index(args, world):
 _PMC_FILE = "r04_pmc_traffic.json"
 # roofline key -> (kernels whose launches are counted, helper kernels whose bytes are added to them)
 _PMC_KERNELS = {"conv_wgrad<bf16,CONV3>(+reduce)": (("wgrad3_tr16_kernel", "wgrad_dma_kernel<9,"), ("wgrad_reduce3_wide",)),
-                "conv_igemm<bf16,CONV3,BN128>": (("conv3_m16_kernel<16, 0>", "conv3_m16_kernel<8, 0>", "conv3_ring64_kernel",
+                "conv_igemm<bf16,CONV3,BN128>": (("conv3_m16_kernel<16, 0, 4>", "conv3_m16_kernel<8, 0, 4>", "conv3_ring64_kernel",
                                                   "conv_igemm_dma_kernel<0, 128,", "conv_igemm_dma_kernel<0, 64, 16"), ()),
-                "conv_igemm<bf16,CONV3,BN128>+bn_bwd_sums": (("conv3_m16_kernel<16, 2>", "conv3_m16_kernel<8, 2>"), ())}
+                "conv_igemm<bf16,CONV3,BN128>+bn_bwd_sums": (("conv3_m16_kernel<16, 2, 4>", "conv3_m16_kernel<8, 2, 4>"), ())}
 _PMC_SOURCES = ("conv_wgrad.hip", "conv_igemm.hip", "conv3_m16.hip", "conv_args.h", "bn.hip", "common.h", "convt_wgrad.hip")
 
 

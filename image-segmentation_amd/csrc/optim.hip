@@ -86,6 +86,36 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamBatch batch, int* _
     }
 }
 
+// found[0] = 1 when any gradient element of the batch is inf / NaN (the caller zeroed it): GradScaler's inf check without
+// its unscale pass -- torch's `_amp_foreach_non_finite_check_and_unscale_` reads AND rewrites every gradient (x 1.0 when
+// the optimizer takes the scale itself) through a multi-tensor launch: 31 us for the U-Net's 31 MB, 75 us for LargeUNet.
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const AdamBatch batch, float* __restrict__ found) {
+    int lo = 0, hi = batch.nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (batch.start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AdamDesc& d = batch.d[lo];
+    const long long base = (long long)((int)blockIdx.x - batch.start[lo]) * CHUNK;
+    long long cnt = d.n - base;
+    if (cnt > CHUNK) cnt = CHUNK;
+    const float* g = d.g + base;
+    bool bad = false;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int nv = (int)(cnt >> 2);
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+            // (x - x is 0 for every finite x and NaN for inf / NaN)
+            const float t = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
+            bad = bad || (t != 0.f);
+        }
+        for (int i = (nv << 2) + threadIdx.x; i < cnt; i += 256) bad = bad || (g[i] - g[i] != 0.f);
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += 256) bad = bad || (g[i] - g[i] != 0.f);
+    }
+    if (bad) found[0] = 1.0f;  // (every writer stores the same value)
+}
+
 // The step counter moves in a launch of its own, behind every adam_kernel launch of the step in stream order (they all
 // read it).  Round 3 let the last block to arrive advance it (arrival count + __threadfence in EVERY block of the last
 // launch): with all the U-Net's tensors in one launch that is a device-scope fence per 4096-element chunk -- measured on
@@ -104,6 +134,28 @@ extern "C" int hipseg_adam_desc_fill(void* host_descs, int index, float* p, cons
     HS_REQUIRE(host_descs && index >= 0 && p && g && m && v && n > 0, "adam_desc_fill: bad arguments");
     AdamDesc& d = reinterpret_cast<AdamDesc*>(host_descs)[index];
     d.p = p, d.g = g, d.m = m, d.v = v, d.n = n;
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_grads_nonfinite(const void* host_descs, int ntensors, float* found, hipseg_stream_t stream) {
+    HS_REQUIRE(host_descs && found && ntensors > 0, "grads_nonfinite: null table or no tensors");
+    const AdamDesc* all = reinterpret_cast<const AdamDesc*>(host_descs);
+    for (int t0 = 0; t0 < ntensors; t0 += MAXT) {
+        AdamBatch b;
+        b.nt = ntensors - t0 < MAXT ? ntensors - t0 : MAXT;
+        long nblk = 0;
+        for (int i = 0; i < b.nt; ++i) {
+            HS_REQUIRE(all[t0 + i].g && all[t0 + i].n > 0, "grads_nonfinite: bad descriptor %d", t0 + i);
+            b.d[i] = all[t0 + i];
+            b.start[i] = (int)nblk;
+            nblk += (all[t0 + i].n + CHUNK - 1) / CHUNK;
+        }
+        b.start[b.nt] = (int)nblk;
+        HS_REQUIRE(nblk < (1l << 31), "grads_nonfinite: too many elements in one launch");
+        hipLaunchKernelGGL(grads_nonfinite_kernel, dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b,
+                           found);
+        HS_LAUNCH_CHECK("grads_nonfinite");
+    }
     return HIPSEG_OK;
 }
 

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "hipseg_decode_records": (I, [P, P, P, P, P, I, I, I, P]),
     "hipseg_adam_desc_size": (c_size_t, []),
     "hipseg_adam_desc_fill": (I, [P, I, P, P, P, P, L]),
+    "hipseg_grads_nonfinite": (I, [P, I, P, P]),
     "hipseg_adam_step": (I, [P, I, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
     "hipseg_augment_workspace_elems": (c_size_t, [I]),
     "hipseg_augment_params": (I, [P, P, I, I] + [c_float] * 9 + [P]),

@@ -4,14 +4,25 @@ Drop-in for `torch.optim.Adam` where the reference's wrappers take `optimizer_cl
 (models/model_wrappers.py:40-41,124: `optim.Adam`, `{'lr': 0.001, 'weight_decay': 1e-4}`), stepped through
 `GradScaler.step` (model_wrappers.py:176,979).  GradScaler hands `found_inf` / `grad_scale` to optimisers that declare
 `_step_supports_amp_scaling`; the kernel divides by the scale and skips the whole step on overflow, so no host sync
-and the step is hipGraph-capturable (the step counter lives on the device)."""
+and the step is hipGraph-capturable (the step counter lives on the device).
+`step` also accepts GradScaler's (deprecated but still offered) `grad_scaler=` hand-over: the optimiser then runs the inf
+check itself -- one read-only pass (hipseg_grads_nonfinite) instead of torch's unscale pass, which rewrites every gradient
+x 1.0 for optimisers that take the scale themselves (31 us + two fills + two copies per U-Net step).  When a torch
+release stops offering it, `found_inf` / `grad_scale` arrive as attributes as before and nothing else changes."""
 import ctypes
+import os
+import warnings
 
 import torch
 
 from . import _lib as L
 from . import ops as _ops
 from .ops import _require_gpu, _stream, ptr
+
+
+# GradScaler announces on every first call that it will stop passing itself to `step(grad_scaler=)`; this optimiser works
+# with and without that hand-over (see the module docstring), so the notice carries no information for its users
+warnings.filterwarnings("ignore", message="GradScaler is going to stop passing itself", category=FutureWarning)
 
 
 class Adam(torch.optim.Optimizer):
@@ -79,14 +90,46 @@ class Adam(torch.optim.Optimizer):
         return host
 
     # ------------------------------------------------------------------ step
+    def _amp_from_scaler(self, scaler):
+        """GradScaler handed itself over (`grad_scaler=`): do what its `step` would have done before calling us --
+        `_check_inf_per_device` when the gradients are still scaled (here: one read-only pass over them), else the
+        `found_inf` that `unscale_` recorded -- and return (found_inf, grad_scale) for the kernel."""
+        from torch.amp.grad_scaler import OptState
+
+        ost = scaler._per_optimizer_states[id(self)]
+        if ost["stage"] is OptState.READY:
+            found = None
+            for gi, group in enumerate(self.param_groups):
+                if not group["params"]:
+                    continue
+                st = self._group_state(gi, group)
+                active = [p for p in st["params"] if p.grad is not None]
+                if not active:
+                    continue
+                if found is None:
+                    found = st.get("found")
+                    if found is None:
+                        found = st["found"] = torch.zeros(1, device=active[0].device)
+                    found.zero_()
+                L.grads_nonfinite(ctypes.addressof(self._table(st, active)), len(active), ptr(found), _stream())
+            if found is None:
+                raise AssertionError("No inf checks were recorded for this optimizer.")
+            ost["found_inf_per_device"] = {found.device: found}  # (what scaler.update() reads)
+            return found, scaler._get_scale_async()
+        found = sum(t.to(next(iter(ost["found_inf_per_device"])), non_blocking=True) for t in ost["found_inf_per_device"].values())
+        return found, None  # (unscale_() was called: the gradients are already unscaled)
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scaler=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        found_inf = getattr(self, "found_inf", None)
-        grad_scale = getattr(self, "grad_scale", None)
+        if grad_scaler is not None:
+            found_inf, grad_scale = self._amp_from_scaler(grad_scaler)
+        else:
+            found_inf = getattr(self, "found_inf", None)
+            grad_scale = getattr(self, "grad_scale", None)
         for gi, group in enumerate(self.param_groups):
             if not group["params"]:
                 continue
@@ -149,6 +192,13 @@ class Adam(torch.optim.Optimizer):
                 st = self._group_state(gi, group)
                 out += [st["flat"][0], st["flat"][1], st["counter"]]
         return out
+
+    if os.environ.get("HIPSEG_NO_FUSED_INF_CHECK"):  # A/B switch: GradScaler's own unscale / inf-check pass
+        _step_with_scaler = step
+
+        @torch.no_grad()
+        def step(self, closure=None):  # noqa: F811  (no `grad_scaler` parameter: GradScaler keeps its own inf check)
+            return type(self)._step_with_scaler(self, closure)
 
     def step_count(self, group=0):
         """number of applied (non-skipped) steps of a group (host sync).  The count is PER GROUP (one device counter),

@@ -370,12 +370,19 @@ int hipseg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H,
 int hipseg_decode_records(const uint8_t* images, const uint8_t* masks, float* out_images, int64_t* out_masks,
                           int* cat_flags, int n, int H, int W, hipseg_stream_t stream);
 
+/* found[0] = 1.0f when any gradient element of the descriptors' tensors is inf or NaN (the caller zeroes found[0] first;
+ * untouched otherwise).  The inf check GradScaler.step needs, without torch's unscale pass over the gradients (which
+ * rewrites every element x 1.0 when the optimizer takes the scale itself, as hipseg_adam_step does).
+ * replaces: aten::_amp_foreach_non_finite_check_and_unscale_ as called by GradScaler._check_inf_per_device
+ *           (models/model_wrappers.py:176 `scaler.step(optimizer)`). */
+int hipseg_grads_nonfinite(const void* host_descs, int ntensors, float* found, hipseg_stream_t stream);
+
 /* ---- optimiser step ----------------------------------------------------------------------------------
  * replaces: torch.optim.Adam.step as driven by GradScaler.step (models/model_wrappers.py:124,176,979): the whole
- * parameter group in ceil(ntensors / 64) launches.  host_descs: HOST table of hipseg_adam_desc_size()-byte entries
+ * parameter group in ceil(ntensors / 88) launches + a one-thread launch that advances the step counter.  host_descs: HOST table of hipseg_adam_desc_size()-byte entries
  * {param, grad, exp_avg, exp_avg_sq (device fp32 pointers), numel} filled by hipseg_adam_desc_fill; it is read during
  * the call only (descriptors travel by value in the kernel arguments).
- * state: device int[2] {step count, internal arrival counter (0)}.  found_inf / grad_scale: device floats or NULL
+ * state: device int[2] {step count, reserved}.  found_inf / grad_scale: device floats or NULL
  * (GradScaler contract: found_inf != 0 skips the step entirely; gradients are divided by grad_scale). */
 size_t hipseg_adam_desc_size(void);
 int hipseg_adam_desc_fill(void* host_descs, int index, float* p, const float* g, float* m, float* v, long n);

@@ -298,3 +298,68 @@ def test_convblock_with_batchnorm_on_load_equals_per_op_path(hs):
         res.append([y.detach(), x.grad] + [p.grad.clone() for p in m.parameters()] + [b.clone() for b in m.buffers()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_hip_adam_through_gradscaler_with_its_own_inf_check(hs):
+    """`scaler.step(opt)` / `scaler.update()` exactly as models/model_wrappers.py:175-177 drives them, hipseg.optim.Adam (which
+    takes GradScaler's `grad_scaler=` hand-over and runs the inf check itself: hipseg_grads_nonfinite) against
+    torch.optim.Adam under its own GradScaler: an inf and a NaN gradient on two of the steps must skip those steps, back
+    the scale off identically, and leave both parameter sets in step; also after scaler.unscale_(opt), and replayed as a
+    hipGraph."""
+    from hipseg.optim import Adam
+
+    torch.manual_seed(3)
+    shapes = [(64, 32, 3, 3), (515,), (7,), (128, 64, 2, 2)]
+    p_ref = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    p_hip = [p.detach().clone().requires_grad_(True) for p in p_ref]
+    kw = dict(lr=1e-2, weight_decay=1e-3)
+    o_ref, o_hip = torch.optim.Adam(p_ref, **kw), Adam(p_hip, **kw)
+    s_ref = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=3)
+    s_hip = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=3)
+    for sc in (s_ref, s_hip):
+        sc.scale(torch.zeros(1, device="cuda"))  # (creates the scale tensors, as scaler.scale(loss) does in a real step)
+    for it in range(9):
+        for ps, sc in ((p_ref, s_ref), (p_hip, s_hip)):
+            g = torch.Generator(device="cuda").manual_seed(100 + it)
+            for k, p in enumerate(ps):
+                grad = torch.randn(p.shape, device="cuda", generator=g) * float(sc.get_scale())  # "scaled" gradients
+                if it == 2 and k == 1:
+                    grad[17] = float("inf")
+                if it == 5 and k == 3:
+                    grad[3, 2, 1, 0] = float("nan")
+                p.grad = grad
+        if it == 7:  # the explicit-unscale order of use (gradient clipping etc.)
+            s_ref.unscale_(o_ref)
+            s_hip.unscale_(o_hip)
+        s_ref.step(o_ref)
+        s_hip.step(o_hip)
+        s_ref.update()
+        s_hip.update()
+        assert float(s_ref.get_scale()) == float(s_hip.get_scale()), it
+        for a, b in zip(p_ref, p_hip):
+            assert torch.isfinite(b).all()
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert o_hip.step_count() == 7  # two of the nine steps were skipped
+    # replayed as a hipGraph (static gradient buffers): the inf check, the step and the scale update are all captured
+    for p in p_hip:
+        p.grad = torch.zeros_like(p)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        s_hip.step(o_hip)
+        s_hip.update()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            s_hip.step(o_hip)
+            s_hip.update()
+        before = o_hip.step_count()
+        scale0 = float(s_hip.get_scale())
+        p_hip[0].grad.fill_(float("inf"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert o_hip.step_count() == before and float(s_hip.get_scale()) == scale0 * 0.5
+        p_hip[0].grad.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert o_hip.step_count() == before + 1
+    torch.cuda.current_stream().wait_stream(st)
