@@ -66,3 +66,45 @@ extern "C" int hipseg_stream_wait_event(hipseg_stream_t stream, void* event) {
     }
     return HIPSEG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Gradient-bucket all-reduce (average) over RCCL for hosts that own an RCCL communicator themselves
+// (`bucket_allreduce(ptr, count, dtype, comm, stream)`; replaces the NCCL all-reduce torch DDP issues
+// per bucket for /root/reference/scripts/train_distributed.py:35).  The Python host of this repo goes through
+// torch.distributed instead (its process group owns the communicator and does not hand it out): hipseg/ddp.py.
+// RCCL is bound at the first call (dlopen of the librccl the process already has, else the system's), so libhipseg.so
+// itself carries no link-time dependency on it.
+#include <dlfcn.h>
+
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+nccl_allreduce_fn rccl_allreduce() {
+    static nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");  // (a process that imported torch has its RCCL loaded already)
+        if (!sym) {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+                if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                    sym = dlsym(h, "ncclAllReduce");
+                    if (sym) break;
+                }
+            }
+        }
+        return reinterpret_cast<nccl_allreduce_fn>(sym);
+    }();
+    return fn;
+}
+}  // namespace
+
+extern "C" int hipseg_bucket_allreduce(void* bucket, size_t count, int dtype, void* comm, hipseg_stream_t stream) {
+    HS_REQUIRE(bucket && count > 0 && comm, "bucket_allreduce: null bucket / communicator or empty bucket");
+    HS_REQUIRE(dtype == HIPSEG_F32, "bucket_allreduce: gradient buckets are fp32 (dtype %d)", dtype);
+    nccl_allreduce_fn fn = rccl_allreduce();
+    HS_REQUIRE(fn, "bucket_allreduce: no RCCL in this process (ncclAllReduce not found)");
+    constexpr int kNcclFloat32 = 7, kNcclAvg = 4;  // ncclDataType_t / ncclRedOp_t of rccl.h (checked in the GPU test)
+    const int rc = fn(bucket, bucket, count, kNcclFloat32, kNcclAvg, comm, reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) {
+        hipseg_set_error("bucket_allreduce: ncclAllReduce returned %d", rc);
+        return HIPSEG_EHIP;
+    }
+    return HIPSEG_OK;
+}

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "hipseg_event_destroy": (I, [P]),
     "hipseg_event_record_external": (I, [P, P]),
     "hipseg_stream_wait_event": (I, [P, P]),
+    "hipseg_bucket_allreduce": (I, [P, c_size_t, I, P, P]),
     "hipseg_conv_affine_relu": (I, [I, P, I, P, I, P, P, P, P, I, I, I, I, P]),
     "hipseg_conv3_bnrelu_in_applies": (I, [I, I, I, I, I, I]),
     "hipseg_conv3_bnrelu_in": (I, [I, P, I, P, P, P, P, P, I, P, I, I, I, P]),

@@ -47,7 +47,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

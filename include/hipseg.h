@@ -426,6 +426,14 @@ int hipseg_event_destroy(void* event);
 int hipseg_event_record_external(void* event, hipseg_stream_t stream);
 int hipseg_stream_wait_event(hipseg_stream_t stream, void* event);
 
+/* Average one flat fp32 gradient bucket over the ranks of an RCCL communicator, in place, on `stream`
+ * (ncclAllReduce(ncclFloat32, ncclAvg)): SURVEY section 8b's `bucket_allreduce(ptr, count, dtype, comm, stream)` for hosts
+ * that own the communicator (`comm` = ncclComm_t).  RCCL is bound at the first call (the librccl already in the process,
+ * else the system's); the Python host of this repo reduces through torch.distributed instead (hipseg/ddp.py: its
+ * process group owns the communicator and does not hand it out).
+ * replaces: the per-bucket NCCL all-reduce of torch DDP (scripts/train_distributed.py:35, models/model_wrappers.py:978). */
+int hipseg_bucket_allreduce(void* bucket, size_t count, int dtype, void* comm, hipseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

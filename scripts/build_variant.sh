@@ -18,5 +18,5 @@ objs=""
 for o in pack bn pointwise loss records augment optim sync conv_igemm conv3_m16 convt_stream conv_wgrad convt_wgrad block; do
   if [[ " $bases " == *" $o "* ]]; then objs="$objs hipseg/lib/${o}_$tag.o"; else objs="$objs hipseg/lib/$o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hipseg/lib/libhipseg_$tag.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hipseg/lib/libhipseg_$tag.so $objs -ldl
 echo built hipseg/lib/libhipseg_$tag.so

@@ -363,3 +363,57 @@ def test_hip_adam_through_gradscaler_with_its_own_inf_check(hs):
         torch.cuda.synchronize()
         assert o_hip.step_count() == before + 1
     torch.cuda.current_stream().wait_stream(st)
+
+
+def test_bucket_allreduce_through_a_raw_rccl_communicator(hs):
+    """hipseg_bucket_allreduce (SURVEY 8b's bucket_allreduce(ptr, count, dtype, comm, stream)) with a communicator the HOST
+    owns: a one-rank RCCL communicator created through RCCL's C API (ctypes), as a non-Python host would; the average
+    over one rank is the identity, the call must run on the given stream and leave the bucket unchanged.  The two enum
+    values the entry point hard-codes (ncclFloat32 = 7, ncclAvg = 4) are checked against rccl.h where the header exists."""
+    import ctypes
+    import os
+    import re
+
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if os.path.exists(hdr):
+        txt = open(hdr).read()
+        assert re.search(r"ncclFloat32\s*=\s*7\b", txt) and re.search(r"ncclAvg\s*=\s*4\b", txt)
+
+    L, ops = hs.L, hs.ops
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        import glob, os
+        cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+        assert cands, "no RCCL library found"
+        rccl = ctypes.CDLL(cands[0])
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        b = torch.randn(100003, device="cuda")
+        want = b.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            L.bucket_allreduce(ops.ptr(b), b.numel(), L.F32, comm.value, s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(b, want)
+        with pytest.raises(Exception, match="bucket_allreduce"):
+            L.bucket_allreduce(ops.ptr(b), b.numel(), L.BF16, comm.value, s.cuda_stream)
+        with pytest.raises(Exception, match="bucket_allreduce"):
+            L.bucket_allreduce(ops.ptr(b), b.numel(), L.F32, 0, s.cuda_stream)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
