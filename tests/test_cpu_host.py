@@ -665,3 +665,27 @@ def test_bench_ladder_end_to_end_subprocess(tmp_path):
     assert r.stdout.strip() == ""
     assert "injected failure of loop 'graph'" in r.stderr and "loop 'graph' failed (exit code 3)" in r.stderr
     assert "starting fresh workers with 'eager'" in r.stderr and "ladder exhausted" in r.stderr
+
+
+def test_bench_two_ranks_under_torchrun_walk_the_ladder_in_lockstep(tmp_path):
+    """the driver's N > 1 command line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) on this
+    GPU-less box: both rank supervisors find each other through the Agreement directory (keyed by the torchrun agent's pid),
+    every loop of the ladder fails on both ranks (no GPU), and BOTH supervisors start each next loop together and give up
+    together -- three attempts each, no rank left waiting out a rendezvous timeout."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the loops would succeed (covered by the -m gpu rehearsal)")
+    env = dict(os.environ, HIPSEG_BENCH_ATTEMPT_TIMEOUT="120")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    lines = r.stderr.splitlines()
+    for rank in (0, 1):
+        for loop, nxt in (("evgraph", "starting fresh workers with 'eager'"), ("eager", "starting fresh workers with 'splitgraph'")):
+            assert any(f"[bench supervisor rank {rank}] loop '{loop}' failed" in l and nxt in l for l in lines), \
+                (rank, loop, r.stderr[-3000:])
+    # (torchrun terminates the other rank as soon as the first one exits non-zero: the last line is certain for one rank only)
+    assert any("loop 'splitgraph' failed" in l and "ladder exhausted" in l for l in lines), r.stderr[-3000:]
+    assert "{\"metric\"" not in r.stdout
