@@ -435,6 +435,18 @@ class Agreement:
                     return True
         return False
 
+    def close(self, timeout=15.0):
+        """every supervisor is done with the directory: rank 0 removes it once all ranks have said so (or after `timeout`)"""
+        import shutil
+
+        self._put(f"done.r{self.rank}", "1")
+        if self.rank != 0:
+            return
+        t0 = time.time()
+        while time.time() - t0 < timeout and not all(self._get(f"done.r{r}") for r in range(self.world)):
+            time.sleep(0.1)
+        shutil.rmtree(self.dir, ignore_errors=True)
+
     def outcome(self, attempt, timeout):
         """{rank: rc} once every rank has reported (a rank still missing after `timeout` is None)."""
         t0 = time.time()
@@ -449,14 +461,25 @@ def supervise(args, world, start=run_child, agreement=None, rank=None):
     """the ladder (see the module docstring).  `start` / `agreement` / `rank` are injectable for the CPU tests of the
     ladder logic."""
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    agree = agreement if agreement is not None else (Agreement(world, rank) if world > 1 else None)
+    tmp = tempfile.mkdtemp(prefix="hipseg_bench_")  # the workers' stderr files (already relayed when this returns)
+    try:
+        return _supervise(args, world, start, agree, rank, tmp)
+    finally:
+        import shutil
+
+        shutil.rmtree(tmp, ignore_errors=True)
+        if agree is not None and hasattr(agree, "close"):
+            agree.close()
+
+
+def _supervise(args, world, start, agree, rank, tmp):
     loops = ladder_for(args.loop, world, bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP")))
     first_limit = float(os.environ.get("HIPSEG_BENCH_ATTEMPT_TIMEOUT", "300"))
     base_port = int(os.environ.get("MASTER_PORT", "29533"))
     argv = [a for i, a in enumerate(sys.argv[1:]) if a != "--loop" and (i == 0 or sys.argv[i] != "--loop")
             and not a.startswith("--loop=")]
     failures = []
-    tmp = tempfile.mkdtemp(prefix="hipseg_bench_")
-    agree = agreement if agreement is not None else (Agreement(world, rank) if world > 1 else None)
     for attempt, loop in enumerate(loops):
         # a fresh rendezvous per attempt: rank 0's worker hosts a new TCPStore (a failed attempt leaves its keys --
         # the RCCL unique id among them -- in the old one).  N > 1: the port is one rank 0's supervisor found free and
