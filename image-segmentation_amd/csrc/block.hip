@@ -29,6 +29,7 @@ static int conv_bn_relu(const hipseg_convblock_t* a, const void* in0, int c0, co
             return rc;
         if (int rc = hipseg_bn_eval_params(g, be, rm, rv, a->eps, C, mean, invstd, scale, shift, s)) return rc;
     }
+    if (!act) return HIPSEG_OK;  // (applied by the consumer on load, see hipseg_convblock_forward)
     return hipseg_bn_relu_apply(dt, raw, scale, shift, act, B, H, W, C, pool, s);
 }
 
@@ -43,9 +44,12 @@ static bool bn_on_load(const hipseg_convblock_t* a) {
 }
 
 extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stream_t s) {
-    HS_REQUIRE(a && a->x0 && a->wp1 && a->wp2 && a->raw1 && a->a1 && a->raw2 && a->out && a->bn1 && a->bn2,
+    HS_REQUIRE(a && a->x0 && a->wp1 && a->wp2 && a->raw1 && a->a1 && a->raw2 && a->bn1 && a->bn2,
                "convblock_forward: null operand");
     HS_REQUIRE(!a->train || a->stats, "convblock_forward: train mode needs the statistics workspace");
+    // out == NULL: the consumer applies the second layer's BatchNorm + ReLU itself when it loads raw2 (bn2 holds scale /
+    // shift): hipseg_head_fwd_bnrelu.  Train mode without a pool only (what that consumer implements).
+    HS_REQUIRE(a->out || (a->train && !a->pool), "convblock_forward: out may be NULL only in train mode without a pool");
     if (bn_on_load(a)) {
         // conv -> statistics -> (scale, shift); the activated intermediate a1 is NOT written: the second convolution
         // transforms raw1 on load
@@ -65,6 +69,7 @@ extern "C" int hipseg_convblock_forward(const hipseg_convblock_t* a, hipseg_stre
                                         (double)B * H * W, a->g2, a->be2, a->eps, a->momentum, a->rm2, a->rv2, a->nbt2, bn2,
                                         bn2 + C, bn2 + 2 * (size_t)C, bn2 + 3 * (size_t)C, s))
             return rc;
+        if (!a->out) return HIPSEG_OK;
         return hipseg_bn_relu_apply(dt, a->raw2, bn2 + 2 * (size_t)C, bn2 + 3 * (size_t)C, a->out, B, H, W, C, a->pool, s);
     }
     if (int rc = conv_bn_relu(a, a->x0, a->C0, a->x1, a->C1, a->wp1, a->b1, a->g1, a->be1, a->rm1, a->rv1, a->nbt1, a->raw1,
@@ -104,7 +109,11 @@ extern "C" int hipseg_convblock_backward(const hipseg_convblock_t* a, hipseg_str
     // until d(raw1) exists, i.e. two distinct buffers
     const bool pair = a->draw1 != a->draw2 && hipseg_conv_wgrad_pair_applies(dt, a->C0, a->C1, C, C, B, H, W);
     // second conv layer
-    if (int rc = bn_relu_bwd(a, a->dout, a->dout2, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s)) return rc;
+    // (dout_rows > 0: the kernel that produced dout -- hipseg_head_bwd_bnrelu -- already left that many rows of this
+    // layer's reduction in a->partial)
+    HS_REQUIRE(a->dout_rows >= 0 && (!a->dout_rows || (!a->pool && !a->dout2)), "convblock_backward: dout_rows");
+    if (int rc = bn_relu_bwd(a, a->dout, a->dout2, a->raw2, a->bn2, a->pool, a->sums2, a->db2, a->draw2, s, a->dout_rows))
+        return rc;
     if (bn_on_load(a)) {  // (a1 was never written: the weight gradient transforms raw1 on load)
         if (int rc = hipseg_conv_wgrad_bnrelu_p(dt, a->raw1, C, a->bn1 + 2 * (size_t)C, a->bn1 + 3 * (size_t)C, a->draw2, C,
                                                 a->dw2, a->slabs, B, H, W, s))

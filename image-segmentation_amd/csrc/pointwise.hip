@@ -233,10 +233,15 @@ __global__ __launch_bounds__(64) void stem_bwd_finalize_kernel(const float* __re
 // ------------------------------------------------------------------ head: NHWC -> NCHW fp32 logits
 constexpr int MAXHC = 8;  // head output channels
 
-template <typename T, int V>
+// ONLOAD (round 4, hipseg_head_fwd_bnrelu): x is the PRE-normalisation output of the last ConvBlock's second convolution
+// and the head runs over round_T(relu(x * scale[c] + shift[c])) -- that block's final BatchNorm + ReLU applied in the
+// head's load path, so the activated tensor and the bn_relu_apply pass that wrote it never exist (the value is rounded
+// to T exactly as that pass would have stored it: results are bit-identical to the two-kernel form).
+template <typename T, int V, bool ONLOAD = false>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ logits, int B,
-                                                        long HW, int Cin, int Cout) {
+                                                        long HW, int Cin, int Cout, const float* __restrict__ scale = nullptr,
+                                                        const float* __restrict__ shift = nullptr) {
     const long npix = (long)B * HW;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         float o[MAXHC];
@@ -247,6 +252,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
         for (int c = 0; c < Cin; c += V) {
             float v[V];
             ldv<T, V>(x + p * Cin + c, v);
+            if constexpr (ONLOAD) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] = to_f32(from_f32<T>(fmaxf(0.f, v[e] * scale[c + e] + shift[c + e])));
+            }
 #pragma unroll
             for (int co = 0; co < MAXHC; ++co)
                 if (co < Cout) {
@@ -262,30 +271,54 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 }
 
 // dx[p][c] = sum_co dl[co][p] w[co][c];  partial[blk][Cout][Cin+1]: dW rows, last column = db
-template <typename T, int V>
+// ONLOAD (hipseg_head_bwd_bnrelu): x is the pre-normalisation tensor (see head_fwd_kernel) -- dW is taken against
+// round_T(relu(x * scale + shift)) -- and, with x and dx both in registers, the block also reduces the BatchNorm-backward
+// sums of that layer, bnp[blk][2][Cin] = [sum g | sum g * xhat] with g = round_T(dx) where x * scale + shift > 0
+// (PixelCtx::finish's rule; rows in bn_bwd_reduce_kernel's layout): the bn_bwd_reduce launch that would re-read dx and x
+// is not needed (hipseg_convblock_t::dout_rows).
+// HC: compile-time bound of the head's output channels (4 or 8): the per-lane dW accumulators and weights are HC x V
+// registers each, and the U-Nets' 3-class head at HC = 8 would carry 128 registers of zeros.
+template <typename T, int V, bool ONLOAD = false, int HC = MAXHC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dl,
                                                         const float* __restrict__ w, T* __restrict__ dx,
                                                         float* __restrict__ partial, int B, long HW, int Cin, int Cout,
-                                                        int CG, int PL, long ppb) {
+                                                        int CG, int PL, long ppb, const float* __restrict__ mean = nullptr,
+                                                        const float* __restrict__ invstd = nullptr,
+                                                        const float* __restrict__ scale = nullptr,
+                                                        const float* __restrict__ shift = nullptr,
+                                                        float* __restrict__ bnp = nullptr) {
     __shared__ float red[2048 + 256];  // PL rows of (Cin + 1): PL * Cin <= 2048, PL <= 256
     const int tid = threadIdx.x;
     const int cg = tid % CG, pl = tid / CG;
-    float aw[MAXHC][V], ab[MAXHC];
+    float aw[HC][V], ab[HC];
 #pragma unroll
-    for (int co = 0; co < MAXHC; ++co) {
+    for (int co = 0; co < HC; ++co) {
         ab[co] = 0.f;
 #pragma unroll
         for (int e = 0; e < V; ++e) aw[co][e] = 0.f;
     }
     const long npix = (long)B * HW;
-    if (pl < PL) {
-        float wv[MAXHC][V];
+    float s1[ONLOAD ? V : 1], s2[ONLOAD ? V : 1];
 #pragma unroll
-        for (int co = 0; co < MAXHC; ++co)
+    for (int e = 0; e < (ONLOAD ? V : 1); ++e) s1[e] = s2[e] = 0.f;
+    if (pl < PL) {
+        float mn[ONLOAD ? V : 1], is[ONLOAD ? V : 1], sc[ONLOAD ? V : 1], sh[ONLOAD ? V : 1];
+        if constexpr (ONLOAD) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                mn[e] = mean[cg * V + e];
+                is[e] = invstd[cg * V + e];
+                sc[e] = scale[cg * V + e];
+                sh[e] = shift[cg * V + e];
+            }
+        }
+        float wv[HC][V];
+#pragma unroll
+        for (int co = 0; co < HC; ++co)
 #pragma unroll
             for (int e = 0; e < V; ++e) wv[co][e] = w[(co < Cout ? co : Cout - 1) * Cin + cg * V + e];
 #pragma unroll
-        for (int co = 0; co < MAXHC; ++co)
+        for (int co = 0; co < HC; ++co)
 #pragma unroll
             for (int e = 0; e < V; ++e) wv[co][e] = co < Cout ? wv[co][e] : 0.f;
         const long start = blockIdx.x * ppb;
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         constexpr int UNR = 4;  // pixels in flight per lane
         const unsigned hw_n = (unsigned)HW;  // 32-bit divides (launch condition: B*HW < 2^31)
         for (long p0 = start + pl; p0 < end; p0 += (long)PL * UNR) {
-            float xv[UNR][V], g[UNR][MAXHC];
+            float xv[UNR][V], g[UNR][HC];
             bool ok[UNR];
             long pc[UNR];
 #pragma unroll
@@ -311,18 +344,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
             for (int u = 0; u < UNR; ++u) {
                 const unsigned pu = (unsigned)pc[u], n = pu / hw_n, hw = pu - n * hw_n;
 #pragma unroll
-                for (int co = 0; co < MAXHC; ++co)
+                for (int co = 0; co < HC; ++co)
                     g[u][co] = dl[((size_t)n * Cout + (co < Cout ? co : Cout - 1)) * hw_n + hw];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                for (int co = 0; co < MAXHC; ++co) g[u][co] = (ok[u] && co < Cout) ? g[u][co] : 0.f;
+                for (int co = 0; co < HC; ++co) g[u][co] = (ok[u] && co < Cout) ? g[u][co] : 0.f;
                 float o[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = 0.f;
+                float xh[ONLOAD ? V : 1];
+                bool pos[ONLOAD ? V : 1];
+                if constexpr (ONLOAD) {
 #pragma unroll
-                for (int co = 0; co < MAXHC; ++co)
+                    for (int e = 0; e < V; ++e) {
+                        const float raw = xv[u][e], y = raw * sc[e] + sh[e];
+                        xh[e] = (raw - mn[e]) * is[e];
+                        pos[e] = y > 0.f;
+                        xv[u][e] = to_f32(from_f32<T>(fmaxf(0.f, y)));
+                    }
+                }
+#pragma unroll
+                for (int co = 0; co < HC; ++co)
                     if (co < Cout) {
                         ab[co] += g[u][co];
 #pragma unroll
@@ -332,13 +376,38 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                         }
                     }
                 if (ok[u]) stv<T, V>(dx + pc[u] * Cin + cg * V, o);
+                if constexpr (ONLOAD) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float gq = (ok[u] && pos[e]) ? to_f32(from_f32<T>(o[e])) : 0.f;  // dx as stored
+                        s1[e] += gq;
+                        s2[e] += gq * xh[e];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (ONLOAD) {
+        // BatchNorm-backward rows: red[pl][Cin] per sum (PL * Cin <= 2048), column-parallel sums in row order
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+            __syncthreads();
+            if (pl < PL) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) red[pl * Cin + cg * V + e] = arr ? s2[e] : s1[e];
+            }
+            __syncthreads();
+            for (int c = tid; c < Cin; c += 256) {
+                float t = 0.f;
+                for (int j = 0; j < PL; ++j) t += red[j * Cin + c];
+                bnp[((size_t)blockIdx.x * 2 + arr) * Cin + c] = t;
             }
         }
     }
     // block reduction over the pixel lanes, one output channel at a time: red[pl][Cin + 1] (last column = bias sum), then
     // column-parallel sums in row order (see stem_bwd_kernel)
 #pragma unroll
-    for (int co = 0; co < MAXHC; ++co) {
+    for (int co = 0; co < HC; ++co) {
         if (co < Cout) {
             __syncthreads();
             if (pl < PL) {
@@ -608,6 +677,24 @@ extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const f
     return HIPSEG_OK;
 }
 
+extern "C" int hipseg_head_fwd_bnrelu(int dtype, const void* raw, const float* scale, const float* shift, const float* w,
+                                      const float* b, float* logits, int B, int H, int W, int Cin, int Cout,
+                                      hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "head_fwd_bnrelu: bad dtype");
+    HS_REQUIRE(raw && scale && shift && w && b && logits && B > 0 && H > 0 && W > 0 && Cin > 0, "head_fwd_bnrelu: bad arguments");
+    HS_REQUIRE(Cout >= 1 && Cout <= MAXHC, "head_fwd_bnrelu: out_channels %d unsupported (1..%d)", Cout, MAXHC);
+    const int V = vec_for(Cin, dtype);
+    const long HW = (long)H * W;
+    HS_REQUIRE((long)B * HW < (1l << 31), "head_fwd_bnrelu: more than 2^31 pixels");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        hipLaunchKernelGGL((head_fwd_kernel<T_, V_, true>), dim3(grid_for(B * HW)), dim3(256), 0, s, (const T_*)raw, w, b,
+                           logits, B, HW, Cin, Cout, scale, shift);
+    });
+    HS_LAUNCH_CHECK("head_fwd_bnrelu");
+    return HIPSEG_OK;
+}
+
 extern "C" int hipseg_head_bwd_blocks(int B, int H, int W) {
     long nb = ((long)B * H * W + 255) / 256;
     return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
@@ -630,10 +717,49 @@ extern "C" int hipseg_head_bwd(int dtype, const void* x, const float* dlogits, c
     g.ppb = (npix + g.nblk - 1) / g.nblk;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
-        hipLaunchKernelGGL((head_bwd_kernel<T_, V_>), dim3(g.nblk), dim3(256), 0, s, (const T_*)x, dlogits, w, (T_*)dx,
-                           partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb);
+        if (Cout <= 4)
+            hipLaunchKernelGGL((head_bwd_kernel<T_, V_, false, 4>), dim3(g.nblk), dim3(256), 0, s, (const T_*)x, dlogits, w,
+                               (T_*)dx, partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb);
+        else
+            hipLaunchKernelGGL((head_bwd_kernel<T_, V_, false, MAXHC>), dim3(g.nblk), dim3(256), 0, s, (const T_*)x, dlogits,
+                               w, (T_*)dx, partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb);
     });
     HS_LAUNCH_CHECK("head_bwd");
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(Cout * (Cin + 1)), dim3(64), 0, s, partial, g.nblk, Cin, Cout, dw,
+                       db);
+    HS_LAUNCH_CHECK("head_bwd_finalize");
+    return HIPSEG_OK;
+}
+
+extern "C" int hipseg_head_bwd_bnrelu(int dtype, const void* raw, const float* mean, const float* invstd, const float* scale,
+                                      const float* shift, const float* dlogits, const float* w, void* dx, float* partial,
+                                      float* dw, float* db, float* bn_partial, int B, int H, int W, int Cin, int Cout,
+                                      hipseg_stream_t stream) {
+    HS_REQUIRE(dtype == HIPSEG_F32 || dtype == HIPSEG_BF16, "head_bwd_bnrelu: bad dtype");
+    HS_REQUIRE(raw && mean && invstd && scale && shift && dlogits && w && dx && partial && dw && db && bn_partial && B > 0 &&
+                   H > 0 && W > 0,
+               "head_bwd_bnrelu: bad arguments");
+    HS_REQUIRE(Cout >= 1 && Cout <= MAXHC, "head_bwd_bnrelu: out_channels %d unsupported (1..%d)", Cout, MAXHC);
+    const int V = vec_for(Cin, dtype);
+    HS_REQUIRE(Cin / V <= 256 && Cin + 1 <= 2048, "head_bwd_bnrelu: unsupported Cin %d", Cin);
+    const long HW = (long)H * W, npix = (long)B * HW;
+    HS_REQUIRE(npix < (1l << 31), "head_bwd_bnrelu: more than 2^31 pixels");
+    RedGeo g;
+    g.CG = Cin / V;
+    g.PL = 256 / g.CG;
+    g.nblk = hipseg_head_bwd_blocks(B, H, W);
+    g.ppb = (npix + g.nblk - 1) / g.nblk;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_TV(dtype, V, {
+        if (Cout <= 4)
+            hipLaunchKernelGGL((head_bwd_kernel<T_, V_, true, 4>), dim3(g.nblk), dim3(256), 0, s, (const T_*)raw, dlogits, w,
+                               (T_*)dx, partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb, mean, invstd, scale, shift, bn_partial);
+        else
+            hipLaunchKernelGGL((head_bwd_kernel<T_, V_, true, MAXHC>), dim3(g.nblk), dim3(256), 0, s, (const T_*)raw, dlogits,
+                               w, (T_*)dx, partial, B, HW, Cin, Cout, g.CG, g.PL, g.ppb, mean, invstd, scale, shift,
+                               bn_partial);
+    });
+    HS_LAUNCH_CHECK("head_bwd_bnrelu");
     hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(Cout * (Cin + 1)), dim3(64), 0, s, partial, g.nblk, Cin, Cout, dw,
                        db);
     HS_LAUNCH_CHECK("head_bwd_finalize");

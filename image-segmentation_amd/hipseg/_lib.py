@@ -76,6 +76,8 @@ PROTOTYPES = {
     "hipseg_stem_bwd2": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_head_fwd": (I, [I, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_head_bwd_blocks": (I, [I, I, I]),
+    "hipseg_head_fwd_bnrelu": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "hipseg_head_bwd_bnrelu": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_head_bwd": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hipseg_bilinear_fwd": (I, [I, P, P, I, I, I, I, I, I, P]),
     "hipseg_bilinear_bwd": (I, [I, P, P, I, I, I, I, I, I, P]),
@@ -108,7 +110,8 @@ class ConvBlockArgs(ctypes.Structure):
                 + [(n, c_void_p) for n in ("x0", "x1", "wp1", "wp2", "wp1t", "wp2t", "b1", "g1", "be1", "b2", "g2", "be2",
                                             "rm1", "rv1", "rm2", "rv2", "nbt1", "nbt2", "raw1", "a1", "raw2", "out", "bn1",
                                             "bn2", "stats", "dout", "dout2", "draw2", "da1", "draw1", "dx0", "dx1", "dw1", "dw2",
-                                            "db1", "db2", "sums1", "sums2", "partial", "slabs", "colpart")])
+                                            "db1", "db2", "sums1", "sums2", "partial", "slabs", "colpart")]
+                + [("dout_rows", ctypes.c_int32)])
 
 # functions whose int return value is a geometry answer, not a status code
 _PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_conv3_bnrelu_in_applies",

@@ -346,7 +346,7 @@ class _BN:
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
 
 
-def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False, inference=False):
+def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False, inference=False, lazy=False):
     """conv3x3 (+bias, +BN batch statistics in the epilogue) -> BN finalize -> BN-apply+ReLU(+pool).
     Returns (raw conv output, activated output, bn state, data-gradient weight operand or None).
     `inference` (eval mode and no gradient wanted: the validation loops, model_wrappers.py:193-215) without a pool runs
@@ -383,6 +383,8 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
         igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, None, B, H, W)
         L.bn_eval_params(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, cout, ptr(bn.mean), ptr(bn.invstd),
                          ptr(bn.scale), ptr(bn.shift), s)
+    if lazy:  # the consumer applies BatchNorm + ReLU when it loads `raw` (ConvBlockFn with a head)
+        return raw, None, bn, wpt
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     act = nhwc_empty(B, cout, Ho, Wo, x0.dtype, dev)
     _hbm("bn_relu_apply" + ("+pool" if pool else ""), B * H * W * cout * _esz(dt) * (1.25 if pool else 2.0),
@@ -427,9 +429,11 @@ _NO_FUSED_INFERENCE = bool(os.environ.get("HIPSEG_NO_FUSED_INFERENCE"))  # A/B s
 _NO_BLOCK_CALLS = bool(os.environ.get("HIPSEG_NO_BLOCK_CALLS"))  # A/B switch: per-op ctypes calls instead of one per block
 
 
-def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, grad):
+def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, grad,
+                   lazy=False):
     """ConvBlock forward through ONE C call (hipseg_convblock_forward: conv -> BN statistics -> BN-apply+ReLU twice);
-    Python only allocates.  Same kernels, same order as the per-op path (_conv_bn_relu)."""
+    Python only allocates.  Same kernels, same order as the per-op path (_conv_bn_relu).  Returns (out, tensors to save
+    for backward); `lazy`: out is None, the last BN-apply + ReLU is left to the consumer of raw2 (saved[6]) / bn2."""
     import ctypes
 
     B, _, H, W = x0.shape
@@ -440,7 +444,7 @@ def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, 
     else:
         wp1, wp2, wp1t, wp2t = _pack_conv(w1, dt, False), _pack_conv(w2, dt, False), None, None
     raw1, a1, raw2 = (nhwc_empty(B, cout, H, W, td, dev) for _ in range(3))
-    out = nhwc_empty(B, cout, H // 2, W // 2, td, dev) if pool else nhwc_empty(B, cout, H, W, td, dev)
+    out = None if lazy else (nhwc_empty(B, cout, H // 2, W // 2, td, dev) if pool else nhwc_empty(B, cout, H, W, td, dev))
     bnv = _f32(8 * cout, dev)
     stats = _f32(L.conv_mtiles(B, H, W) * 2 * cout, dev) if train else None
     A = L.ConvBlockArgs()
@@ -453,17 +457,26 @@ def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, 
     A.bn1, A.bn2, A.stats = bnv.data_ptr(), bnv.data_ptr() + 16 * cout, ptr(stats)
     L.convblock_forward(ctypes.addressof(A), _stream())
     if grad:
-        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv)
         ctx.train, ctx.pool, ctx.dt, ctx.blk = train, pool, dt, A
         ctx.small = (b1, g1, be1, b2, g2, be2)
-    return out
+        return out, (x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv)
+    return out, ()
 
 
-def _block_backward(ctx, dout, dout2=None):
-    """the matching backward through hipseg_convblock_backward (BN backward x2, weight gradients x2, data gradients)."""
+def _block_partial_rows(dt, B, C, H, W, pool):
+    """rows of BatchNorm-backward partial sums a block's backward may see: the reduce kernels' blocks, the tiles of the
+    data-gradient kernel that reduces the first layer's sums in its epilogue (hipseg_conv3_dgrad_bnstats), or the blocks
+    of the head kernel that reduces the second layer's (hipseg_head_bwd_bnrelu)."""
+    return max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0),
+               L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W), L.head_bwd_blocks(B, H, W))
+
+
+def _block_backward(ctx, dout, dout2=None, reduced=None):
+    """the matching backward through hipseg_convblock_backward (BN backward x2, weight gradients x2, data gradients).
+    `reduced` = (partial, rows): the second layer's BatchNorm-backward rows already sit in that workspace."""
     import ctypes
 
-    x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv = ctx.saved_tensors
+    x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t, bnv = ctx.saved_tensors[:10]
     A, dt, train, pool = ctx.blk, ctx.dt, ctx.train, ctx.pool
     B, C, H, W = raw2.shape
     dev, td = raw2.device, raw2.dtype
@@ -483,11 +496,8 @@ def _block_backward(ctx, dout, dout2=None):
         dx1 = nhwc_empty(B, c1, H, W, td, dev) if c1 else None
     dw1, dw2, db1, db2 = grad_out(w1), grad_out(w2), grad_out(b1), grad_out(b2)
     sums1, sums2 = grad_out_pair(be1, g1), grad_out_pair(be2, g2)
-    # rows of BatchNorm-backward partial sums: the reduce kernels' blocks, or the tiles of the data-gradient kernel that
-    # reduces the first layer's sums in its epilogue (hipseg_conv3_dgrad_bnstats)
-    nblk = max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0),
-               L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W))
-    partial = _f32(nblk * 2 * C, dev)
+    partial = reduced[0] if reduced is not None else _f32(_block_partial_rows(dt, B, C, H, W, pool) * 2 * C, dev)
+    A.dout_rows = reduced[1] if reduced is not None else 0
     slabs = _f32(max(L.wgrad_workspace_elems(L.CONV3, c0 + c1, C, B, H, W), L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W)), dev)
     colpart = None if train else _f32(L.colsum_blocks(B * H * W, C, dt) * C, dev)
     A.dout, A.draw2, A.da1, A.draw1, A.dx0, A.dx1 = ptr(dout), ptr(draw), ptr(da1), ptr(draw1), ptr(dx0), ptr(dx1)
@@ -496,8 +506,47 @@ def _block_backward(ctx, dout, dout2=None):
     A.partial, A.slabs, A.colpart = ptr(partial), ptr(slabs), ptr(colpart)
     A.wp1t, A.wp2t, A.need_dx = ptr(wp1t), ptr(wp2t), int(dx0 is not None)
     L.convblock_backward(ctypes.addressof(A), _stream())
-    return (dx0, dx1, dw1, db1, sums1[C:], sums1[:C], dw2, db2, sums2[C:], sums2[:C], None, None, None, None, None, None,
-            None, None, None, None)
+    return (dx0, dx1, dw1, db1, sums1[C:], sums1[:C], dw2, db2, sums2[C:], sums2[:C])
+
+
+# A/B switch (read by models/processing_blocks.py): last ConvBlock and 1x1 head as two autograd nodes, with the BN-apply,
+# head and BN-backward reduce launches each on their own
+_NO_HEAD_FUSE = bool(os.environ.get("HIPSEG_NO_HEAD_FUSE"))
+
+
+def _head_fwd(dt, x, w, b, bn=None):
+    """1x1 head on NHWC activations -> NCHW fp32 logits; `bn`: x is a pre-normalisation tensor, relu(x * scale + shift)
+    is applied on load (hipseg_head_fwd_bnrelu)."""
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    logits = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    nbytes = B * H * W * (cin * _esz(dt) + cout * 4)
+    if bn is None:
+        _hbm("head_fwd", nbytes, L.head_fwd, dt, ptr(x), ptr(w), ptr(b), ptr(logits), B, H, W, cin, cout, _stream())
+    else:
+        _hbm("head_fwd+bn_relu", nbytes, L.head_fwd_bnrelu, dt, ptr(x), ptr(bn[2]), ptr(bn[3]), ptr(w), ptr(b), ptr(logits),
+             B, H, W, cin, cout, _stream())
+    return logits
+
+
+def _head_bwd(dt, x, dl, w, bias, bn=None, bn_partial=None):
+    """(dx, dw, db) of the head; `bn` = (mean, invstd, scale, shift) and `bn_partial`: the on-load form, which also leaves
+    hipseg_head_bwd_blocks() rows of the layer's BatchNorm-backward sums in bn_partial."""
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    dl = dl.float().contiguous()
+    nblk = L.head_bwd_blocks(B, H, W)
+    part = _f32(nblk * cout * (cin + 1), x.device)
+    dx = nhwc_empty(B, cin, H, W, x.dtype, x.device)
+    dw, db = grad_out(w), grad_out(bias)
+    nbytes = B * H * W * (2 * cin * _esz(dt) + cout * 4)
+    if bn is None:
+        _hbm("head_bwd", nbytes, L.head_bwd, dt, ptr(x), ptr(dl), ptr(w), ptr(dx), ptr(part), ptr(dw), ptr(db), B, H, W, cin,
+             cout, _stream())
+    else:
+        _hbm("head_bwd+bn_bwd_sums", nbytes, L.head_bwd_bnrelu, dt, ptr(x), ptr(bn[0]), ptr(bn[1]), ptr(bn[2]), ptr(bn[3]),
+             ptr(dl), ptr(w), ptr(dx), ptr(part), ptr(dw), ptr(db), ptr(bn_partial), B, H, W, cin, cout, _stream())
+    return dx, dw, db
 
 
 class ConvBlockFn(torch.autograd.Function):
@@ -507,47 +556,94 @@ class ConvBlockFn(torch.autograd.Function):
     `two`: return the output TWICE (the second an alias of the first), one per consumer -- an encoder block's pooled
     output feeds the next block and a decoder block's skip input (models/UNet.py:64-72).  Given one tensor object,
     autograd sums the two gradients in an elementwise pass of its own before this backward runs; with one alias per
-    consumer each gradient arrives on its own and the BatchNorm-backward kernels read both (hipseg_bn_bwd_*2)."""
+    consumer each gradient arrives on its own and the BatchNorm-backward kernels read both (hipseg_bn_bwd_*2).
+    `hw`, `hb`: weight and bias of the 1x1 head that consumes the block's output (models/UNet.py:72-73, dec4 -> out);
+    the function then returns the head's NCHW fp32 logits.  In train mode the block's last BatchNorm + ReLU is applied
+    in the head's load path and the head's backward leaves that layer's BatchNorm-backward sums behind
+    (hipseg_head_fwd_bnrelu / hipseg_head_bwd_bnrelu): two full-resolution passes fewer; otherwise block and head simply
+    run one after the other."""
 
     @staticmethod
     def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool,
-                no_grad=False, two=False):
-        out = ConvBlockFn._forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train,
-                                   pool, no_grad)
+                no_grad=False, two=False, hw=None, hb=None):
+        dt = _dt(x0)
+        # (grad mode is off inside Function.forward, and needs_input_grad stays True for parameters under
+        # torch.no_grad(): the caller passes whether a graph is being recorded at all)
+        grad = any(ctx.needs_input_grad) and not no_grad
+        head = hw is not None
+        if head and (two or pool):
+            raise ValueError("ConvBlockFn: a head consumes the un-pooled output of a block with one consumer")
+        lazy = head and grad and train
+        out, saved = ConvBlockFn._forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2,
+                                          train, pool, grad, lazy)
+        ctx.head = ctx.lazy = False
+        if head:
+            if lazy:  # saved[6] = raw2; scale / shift of its BatchNorm from this forward's statistics
+                logits = _head_fwd(dt, saved[6], hw, hb, ConvBlockFn._bn2(ctx, saved))
+            else:
+                logits = _head_fwd(dt, out, hw, hb)
+            if grad:
+                ctx.head, ctx.lazy, ctx.hbias, ctx.nsaved = True, lazy, hb, len(saved)
+                saved = saved + (hw,) + (() if lazy else (out,))
+        if grad:
+            ctx.save_for_backward(*saved)
+        if head:
+            return logits
         if two:
             ctx.set_materialize_grads(False)  # an unused alias hands None to backward, not a tensor of zeros
             return out, out.detach()
         return out
 
     @staticmethod
-    def _forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, no_grad):
-        dt = _dt(x0)
-        # (grad mode is off inside Function.forward, and needs_input_grad stays True for parameters under
-        # torch.no_grad(): the caller passes whether a graph is being recorded at all)
-        grad = any(ctx.needs_input_grad) and not no_grad
+    def _bn2(ctx, saved):
+        """(mean, invstd, scale, shift) of the second layer's BatchNorm in this forward"""
+        if ctx.blk is not None:
+            bnv = saved[9]
+            C = bnv.numel() // 8
+            return tuple(bnv[(4 + i) * C:(5 + i) * C] for i in range(4))
+        bn = ctx.bn2
+        return bn.mean, bn.invstd, bn.scale, bn.shift
+
+    @staticmethod
+    def _forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, grad, lazy):
         inf = not grad and not train and not _NO_FUSED_INFERENCE  # nothing saved, no backward: fused inference kernels
         ctx.blk = None
         if PROFILE is None and not inf and not _NO_BLOCK_CALLS:  # one C call for the whole block (host cost)
             return _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train,
-                                  pool, grad)
+                                  pool, grad, lazy)
         raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad, inf)
-        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf)
-        if inf:
-            return out
-        ctx.save_for_backward(x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
+        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf, lazy)
+        if inf or not grad:
+            return out, ()
         ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
         ctx.small = (b1, g1, be1, b2, g2, be2)  # leaf parameters: only their gradient destinations are needed
-        return out
+        return out, (x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
 
     @staticmethod
     def backward(ctx, dout, dout2=None):
         if dout is None:
             dout, dout2 = dout2, None
         if dout is None:
-            return (None,) * 20
+            return (None,) * 22
+        tail = (None,) * 10
+        reduced = None
+        if ctx.head:  # dout = d(logits): through the head first
+            saved = ctx.saved_tensors
+            hw = saved[ctx.nsaved]
+            raw2 = saved[6]
+            B, C, H, W = raw2.shape
+            if ctx.lazy:
+                partial = _f32(_block_partial_rows(ctx.dt, B, C, H, W, False) * 2 * C, raw2.device)
+                dout, dhw, dhb = _head_bwd(ctx.dt, raw2, dout, hw, ctx.hbias, ConvBlockFn._bn2(ctx, saved), partial)
+                reduced = (partial, L.head_bwd_blocks(B, H, W))
+            else:
+                dout, dhw, dhb = _head_bwd(ctx.dt, saved[ctx.nsaved + 1], dout, hw, ctx.hbias)
+            tail = tail + (dhw, dhb)
+        else:
+            tail = tail + (None, None)
         if ctx.blk is not None:
-            return _block_backward(ctx, dout, dout2)
-        x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors
+            return _block_backward(ctx, dout, dout2, reduced) + tail
+        x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors[:9]
         dt, train, pool = ctx.dt, ctx.train, ctx.pool
         B, C, H, W = raw2.shape
         dev = raw2.device
@@ -561,7 +657,7 @@ class ConvBlockFn(torch.autograd.Function):
         # and the first layer's BatchNorm-backward sums out of the data-gradient epilogue, where the shapes allow
         pair = bool(L.conv_wgrad_pair_applies(dt, c0, c1, C, C, B, H, W))
         # ---- second conv layer
-        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2, dy2=dout2)
+        draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2, reduced, dy2=dout2)
         dw2 = grad_out(w2)
         if not pair:
             _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
@@ -601,8 +697,7 @@ class ConvBlockFn(torch.autograd.Function):
             dx0 = nhwc_empty(B, c0, H, W, raw2.dtype, dev)
             dx1 = nhwc_empty(B, c1, H, W, raw2.dtype, dev) if c1 else None
             igemm(dt, L.CONV3, draw1, C, None, 0, wp1t, None, dx0, c0, dx1, c1, None, B, H, W)
-        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None, None, None,
-                None)
+        return (dx0, dx1, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2) + tail
 
 
 class ConvT2x2Fn(torch.autograd.Function):

@@ -99,7 +99,7 @@ class ClipAutoencoder(nn.Module):
         inp = _stem(self.input, X)
         bottleneck = self.coupler(clip_features.float()).view(-1, 64, 16, 16)
         d = self.dec3(self.dec2(self.dec1(bottleneck)))
-        return _head(self.out, self.dec4(d, inp))
+        return self.dec4.forward_head(d, inp, self.out)  # last block + 1x1 head: one autograd node
 
 
 class ClipResSegmentationModel(nn.Module):

@@ -60,9 +60,10 @@ class _UNetBase(nn.Module):
                 h, h_skip = enc.forward_two(h)
             skips.append(h_skip)
         h = self.bottleneck(h) if fuse is None else fuse(h, skips)
-        for k in range(1, len(self._dec) + 1):
+        last = len(self._dec)
+        for k in range(1, last):
             h = getattr(self, f"dec{k}")(h, skips[-k])
-        return _head(self.out, h)
+        return getattr(self, f"dec{last}").forward_head(h, skips[-last], self.out)  # last block + 1x1 head: one node
 
     @torch.compiler.disable
     def forward(self, x):

@@ -17,9 +17,10 @@ from hipseg import ops
 
 
 
-def _double_conv(seq, x, skip, pool, two=False):
+def _double_conv(seq, x, skip, pool, two=False, head=None):
     """seq = (conv, bn, relu, conv, bn, relu) parameter container of one ConvBlock.
-    two: (output, alias of the output) for a block whose output has two consumers (see ops.ConvBlockFn)."""
+    two: (output, alias of the output) for a block whose output has two consumers (see ops.ConvBlockFn).
+    head: the 1x1 nn.Conv2d that consumes the block's output; its NCHW fp32 logits are returned instead."""
     c1, n1, _, c2, n2, _ = seq
     td = ops._tdtype(ops.precision())
     x = ops.as_nhwc(x, td)
@@ -33,6 +34,11 @@ def _double_conv(seq, x, skip, pool, two=False):
     train = n1.training
     stats = (n1.running_mean, n1.running_var, n1.num_batches_tracked, n2.running_mean, n2.running_var,
              n2.num_batches_tracked)
+    if head is not None:
+        if head.kernel_size != (1, 1) or head.in_channels != c2.out_channels:
+            raise ValueError(f"head must be a 1x1 convolution over {c2.out_channels} channels")
+        return ops.ConvBlockFn.apply(x, skip, c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight,
+                                     n2.bias, *stats, train, pool, not torch.is_grad_enabled(), two, head.weight, head.bias)
     return ops.ConvBlockFn.apply(x, skip, c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight,
                                  n2.bias, *stats, train, pool, not torch.is_grad_enabled(), two)
 
@@ -97,6 +103,19 @@ class ConvBlockUpsampleSkip(nn.Module):
         if x.shape[2:] != skip.shape[2:]:
             x = ops.BilinearFn.apply(x, skip.shape[2], skip.shape[3])
         return _double_conv(self.conv.conv, x, skip, False)
+
+    @torch.compiler.disable
+    def forward_head(self, x, skip, head):
+        """head(self(x, skip)) for the 1x1 output convolution `head` that follows the LAST decoder block (reference:
+        models/UNet.py:72-73), as NCHW fp32 logits.  One autograd node: in training the block's final BatchNorm + ReLU
+        runs in the head kernel's load path and the head's backward reduces that layer's BatchNorm-backward sums
+        (see ops.ConvBlockFn)."""
+        if ops._NO_HEAD_FUSE:  # A/B switch: two autograd nodes, every launch on its own
+            return ops.HeadFn.apply(self.forward(x, skip), head.weight, head.bias)
+        x = _upsample(self.up, x)
+        if x.shape[2:] != skip.shape[2:]:
+            x = ops.BilinearFn.apply(x, skip.shape[2], skip.shape[3])
+        return _double_conv(self.conv.conv, x, skip, False, head=head)
 
 
 class ConvBlockUpsample(nn.Module):

@@ -82,5 +82,4 @@ class ClipUnetPrompt(nn.Module):
         d = self.dec1(fused, enc3)
         d = self.dec2(d, enc2)
         d = self.dec3(d, enc1)
-        d = self.dec4(d, inp_skip)
-        return self.activation(_head(self.out, d))
+        return self.activation(self.dec4.forward_head(d, inp_skip, self.out))  # last block + 1x1 head: one autograd node

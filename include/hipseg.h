@@ -295,6 +295,11 @@ typedef struct hipseg_convblock {
     const void *dout, *dout2; /* dout2: optional second gradient of `out` (two consumers), see hipseg_bn_bwd_apply2 */
     void *draw2, *da1, *draw1, *dx0, *dx1;
     float *dw1, *dw2, *db1, *db2, *sums1, *sums2, *partial, *slabs, *colpart;
+    /* > 0: `partial` already holds that many [2][Cout] rows of the second layer's BatchNorm-backward reduction, left
+     * there by the kernel that produced dout (hipseg_head_bwd_bnrelu); backward then skips that reduce launch.  Goes
+     * with forward's out == NULL (train mode, no pool): the second layer's BatchNorm + ReLU is applied by the consumer
+     * when it loads raw2 (hipseg_head_fwd_bnrelu), `out` is never written. */
+    int32_t dout_rows;
 } hipseg_convblock_t;
 size_t hipseg_convblock_size(void);
 int hipseg_convblock_forward(const hipseg_convblock_t* args, hipseg_stream_t stream);
@@ -322,6 +327,21 @@ int hipseg_head_bwd_blocks(int B, int H, int W);
 int hipseg_head_bwd(int dtype, const void* x, const float* dlogits_nchw, const float* w, void* dx,
                     float* partial, float* dw, float* db, int B, int H, int W, int Cin, int Cout,
                     hipseg_stream_t stream);
+
+/* head over the LAST ConvBlock's pre-normalisation output (models/UNet.py:72-73: dec4 -> out): that block's final
+ * BatchNorm + ReLU (processing_blocks.py:33-34) is applied in the head's load path -- x := round_dtype(relu(raw * scale +
+ * shift)), the value bn_relu_apply would have stored, so logits / dW / db / dX are bit-identical to
+ * hipseg_bn_relu_apply + hipseg_head_fwd / hipseg_head_bwd -- and the activated tensor never exists.
+ * head_bwd_bnrelu also leaves the BatchNorm-backward partial sums of that layer, bn_partial[hipseg_head_bwd_blocks()][2][Cin]
+ * = [sum g | sum g * xhat] with g = dX where raw * scale + shift > 0 (hipseg_bn_bwd_reduce's rows; hand them to
+ * hipseg_colsum_finalize / hipseg_convblock_t::dout_rows): the reduce pass over dX and raw is not needed. */
+int hipseg_head_fwd_bnrelu(int dtype, const void* raw, const float* scale, const float* shift, const float* w,
+                           const float* b, float* logits_nchw, int B, int H, int W, int Cin, int Cout,
+                           hipseg_stream_t stream);
+int hipseg_head_bwd_bnrelu(int dtype, const void* raw, const float* mean, const float* invstd, const float* scale,
+                           const float* shift, const float* dlogits_nchw, const float* w, void* dx, float* partial,
+                           float* dw, float* db, float* bn_partial, int B, int H, int W, int Cin, int Cout,
+                           hipseg_stream_t stream);
 
 /* ---- bilinear resize, align_corners=True (processing_blocks.py:107), NHWC ---------- */
 int hipseg_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo,

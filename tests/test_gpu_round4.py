@@ -417,3 +417,135 @@ def test_bucket_allreduce_through_a_raw_rccl_communicator(hs):
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("prec,td,dt", [("fp32", torch.float32, 0), ("bf16", torch.bfloat16, 1)])
+@pytest.mark.parametrize("case", [(2, 32, 3, 64, 64), (3, 32, 3, 40, 56), (1, 64, 5, 24, 24), (16, 32, 3, 128, 128)], ids=str)
+def test_head_with_batchnorm_relu_on_load(hs, prec, td, dt, case):
+    """hipseg_head_fwd_bnrelu / hipseg_head_bwd_bnrelu == hipseg_bn_relu_apply followed by hipseg_head_fwd / hipseg_head_bwd,
+    bit for bit (logits, dX, dW, db), and the BatchNorm-backward rows the backward leaves behind finalize to the sums
+    hipseg_bn_bwd_reduce computes from the stored dX (another partition of the same fp32 sum: compared to rounding)."""
+    L, ops = hs.L, hs.ops
+    B, C, K, H, W = case
+    raw = to_dev_nhwc(rnd(T("r4.hd.raw", (B, C, H, W), -2, 2), td), td)
+    mean = T("r4.hd.mean", (C,), -0.3, 0.3).cuda()
+    invstd = T("r4.hd.is", (C,), 0.5, 1.5).cuda()
+    gamma = T("r4.hd.g", (C,), -1.2, 1.2).cuda()
+    beta = T("r4.hd.b", (C,), -0.4, 0.4).cuda()
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    w = T("r4.hd.w", (K, C, 1, 1), -0.5, 0.5).cuda()
+    b = T("r4.hd.bias", (K,), -0.5, 0.5).cuda()
+    dl = T("r4.hd.dl", (B, K, H, W), -1, 1).cuda()
+    s = ops._stream()
+    p = ops.ptr
+    # reference: two kernels forward, three backward
+    act = ops.nhwc_empty(B, C, H, W, td, "cuda")
+    L.bn_relu_apply(dt, p(raw), p(scale), p(shift), p(act), B, H, W, C, 0, s)
+    lg_ref = torch.empty(B, K, H, W, device="cuda")
+    L.head_fwd(dt, p(act), p(w), p(b), p(lg_ref), B, H, W, C, K, s)
+    nb = L.head_bwd_blocks(B, H, W)
+    part = torch.zeros(nb * K * (C + 1), device="cuda")
+    dx_ref, dw_ref, db_ref = ops.nhwc_empty(B, C, H, W, td, "cuda"), torch.zeros(K, C, device="cuda"), torch.zeros(K, device="cuda")
+    L.head_bwd(dt, p(act), p(dl), p(w), p(dx_ref), p(part), p(dw_ref), p(db_ref), B, H, W, C, K, s)
+    nred = L.bn_bwd_blocks(B, H, W, C, dt, 0)
+    rows_ref = torch.zeros(nred, 2, C, device="cuda")
+    L.bn_bwd_reduce2(dt, p(dx_ref), 0, p(raw), p(mean), p(invstd), p(scale), p(shift), p(rows_ref), B, H, W, C, 0, s)
+    sums_ref = torch.zeros(2 * C, device="cuda")
+    L.colsum_finalize(p(rows_ref), nred, 2, C, p(sums_ref), 0, s)
+    # on load
+    lg = torch.empty(B, K, H, W, device="cuda")
+    L.head_fwd_bnrelu(dt, p(raw), p(scale), p(shift), p(w), p(b), p(lg), B, H, W, C, K, s)
+    part2 = torch.zeros(nb * K * (C + 1), device="cuda")
+    dx, dw, db = ops.nhwc_empty(B, C, H, W, td, "cuda"), torch.zeros(K, C, device="cuda"), torch.zeros(K, device="cuda")
+    rows = torch.full((nb, 2, C), float("nan"), device="cuda")
+    L.head_bwd_bnrelu(dt, p(raw), p(mean), p(invstd), p(scale), p(shift), p(dl), p(w), p(dx), p(part2), p(dw), p(db), p(rows),
+                      B, H, W, C, K, s)
+    sums = torch.zeros(2 * C, device="cuda")
+    L.colsum_finalize(p(rows), nb, 2, C, p(sums), 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(lg, lg_ref) and torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    assert float(lg.abs().max()) > 0 and float(dx.float().abs().max()) > 0
+    assert torch.isfinite(rows).all()
+    err = (sums.double() - sums_ref.double()).abs().max()
+    assert err <= 2e-5 * max(1.0, float(sums_ref.abs().max())) * (B * H * W) ** 0.5 * 0.05 + 1e-4, float(err)
+    assert float(sums_ref.abs().max()) > 0
+
+
+def _unet_step_with_head(hs, fuse, prec, per_op=False, train=True):
+    import models.UNet as un
+    from models.losses import HybridLoss
+
+    ops = hs.ops
+    torch.manual_seed(11)
+    m = un.UNet().cuda().train(train)
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(2, 3, 32, 48, generator=g).cuda()
+    t = torch.randint(0, 3, (2, 32, 48), generator=g).cuda()
+    old = ops._NO_HEAD_FUSE, ops._NO_BLOCK_CALLS
+    ops._NO_HEAD_FUSE, ops._NO_BLOCK_CALLS = not fuse, per_op
+    try:
+        with ops.precision_mode(prec):
+            out = m(x)
+            loss = HybridLoss()(out, t)
+        loss.backward()
+    finally:
+        ops._NO_HEAD_FUSE, ops._NO_BLOCK_CALLS = old
+    torch.cuda.synchronize()
+    return out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_unet_last_block_and_head_as_one_node(hs, prec):
+    """models/UNet.py:72-73 (dec4 -> out): with the last block's BatchNorm + ReLU applied in the head's load path and that
+    layer's BatchNorm-backward sums reduced by the head's backward, the logits, the head's gradients and the BatchNorm
+    buffers are bit-identical to the separate launches; every other gradient sits downstream of the re-partitioned fp32
+    sums and is compared to rounding (fp32) / to the storage precision (bf16)."""
+    o0, g0, b0 = _unet_step_with_head(hs, False, prec)
+    o1, g1, b1 = _unet_step_with_head(hs, True, prec)
+    assert torch.equal(o0, o1)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    for k in ("out.weight", "out.bias"):
+        assert torch.equal(g0[k], g1[k]), k
+    rel = 2e-5 if prec == "fp32" else 2e-2
+    for k in g0:
+        d = float((g0[k].double() - g1[k].double()).norm())
+        n = float(g0[k].double().norm())
+        assert d <= rel * max(n, 1e-6), (k, d, n)
+    # the fused form through the per-op launch sequence (bench.py's profiling path) == through the block call
+    o2, g2, _ = _unet_step_with_head(hs, True, prec, per_op=True)
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+
+
+def test_unet_head_node_in_eval_and_no_grad_modes(hs):
+    """outside training the node runs block and head one after the other (no pass to save): the eval-mode step matches
+    the two-node form bit for bit, with and without a graph"""
+    o0, g0, _ = _unet_step_with_head(hs, False, "bf16", train=False)
+    o1, g1, _ = _unet_step_with_head(hs, True, "bf16", train=False)
+    assert torch.equal(o0, o1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    import models.UNet as un
+
+    torch.manual_seed(11)
+    m = un.UNet().cuda().eval()
+    x = torch.rand(2, 3, 32, 48).cuda()
+    ops = hs.ops
+    res = []
+    for off in (True, False):
+        old = ops._NO_HEAD_FUSE
+        ops._NO_HEAD_FUSE = off
+        try:
+            with torch.no_grad(), torch.autocast("cuda"):
+                res.append(m(x))
+        finally:
+            ops._NO_HEAD_FUSE = old
+    with torch.autocast("cuda"):
+        b = m(x)
+    a = res[1]
+    assert torch.equal(res[0], a) and a.dtype == torch.float32 and a.shape == (2, 3, 32, 48)
+    # (without a graph the eval-mode blocks run as fused conv + folded-BatchNorm + ReLU kernels: same values to bf16 rounding)
+    assert (a - b.detach()).abs().max() <= 2e-2 * max(1.0, float(a.abs().max()))
