@@ -346,7 +346,8 @@ class _BN:
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
 
 
-def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False, inference=False, lazy=False):
+def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_t=False, inference=False, lazy=False,
+                  in_bn=None):
     """conv3x3 (+bias, +BN batch statistics in the epilogue) -> BN finalize -> BN-apply+ReLU(+pool).
     Returns (raw conv output, activated output, bn state, data-gradient weight operand or None).
     `inference` (eval mode and no gradient wanted: the validation loops, model_wrappers.py:193-215) without a pool runs
@@ -375,7 +376,12 @@ def _conv_bn_relu(dt, x0, x1, w, b, gamma, beta, rm, rv, nbt, train, pool, need_
     s = _stream()
     if train:
         stats = _f32(L.conv_mtiles(B, H, W) * 2 * cout, dev)
-        igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, stats, B, H, W)
+        if in_bn is not None:  # x0 is a PRE-normalisation tensor: relu(x0 * scale + shift) applied in the load path
+            key = f"conv_igemm<bf16,CONV3,BN{128 if cout > 64 else (64 if cout > 32 else 32)}>"
+            _timed(key, 2.0 * B * H * W * cout * c0 * 9, L.conv3_bnrelu_in, dt, ptr(x0), c0, ptr(in_bn.scale), ptr(in_bn.shift),
+                   ptr(wp), ptr(b), ptr(raw), cout, ptr(stats), B, H, W, s, nbytes=B * H * W * (c0 + cout) * _esz(dt))
+        else:
+            igemm(dt, L.CONV3, x0, c0, x1, c1, wp, b, raw, cout, None, 0, stats, B, H, W)
         rows = L.conv_stats_rows(dt, L.CONV3, c0, c1, cout, 0, B, H, W)
         L.bn_finalize(ptr(stats), rows, cout, float(B * H * W), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm), ptr(rv),
                       ptr(nbt), ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), s)
@@ -427,6 +433,7 @@ def _bn_relu_bwd(dt, dy, raw, bn, train, pool, bias, gamma, beta, reduced=None, 
 
 _NO_FUSED_INFERENCE = bool(os.environ.get("HIPSEG_NO_FUSED_INFERENCE"))  # A/B switch (scripts/bench_infer.py)
 _NO_BLOCK_CALLS = bool(os.environ.get("HIPSEG_NO_BLOCK_CALLS"))  # A/B switch: per-op ctypes calls instead of one per block
+_PEROP_ON_LOAD = True  # the per-op path takes BatchNorm-on-load where the block call does (tests switch it off: materialised reference)
 
 
 def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool, grad,
@@ -611,11 +618,21 @@ class ConvBlockFn(torch.autograd.Function):
         if PROFILE is None and not inf and not _NO_BLOCK_CALLS:  # one C call for the whole block (host cost)
             return _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train,
                                   pool, grad, lazy)
-        raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad, inf)
-        raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf, lazy)
+        # the block call's rule (csrc/block.hip, bn_on_load): first BatchNorm + ReLU in the second convolution's load path
+        B, _, H, W = x0.shape
+        C, c0, c1 = w1.shape[0], x0.shape[1], (x1.shape[1] if x1 is not None else 0)
+        on_load = bool(_PEROP_ON_LOAD and train and not inf and L.conv3_bnrelu_in_applies(dt, C, C, B, H, W)
+                       and L.conv_wgrad_bnrelu_p_applies(dt, C, C, B, H, W)
+                       and not L.conv_wgrad_pair_applies(dt, c0, c1, C, C, B, H, W))
+        raw1, a1, bn1, wp1t = _conv_bn_relu(dt, x0, x1, w1, b1, g1, be1, rm1, rv1, nbt1, train, False, grad, inf, lazy=on_load)
+        if on_load:  # (a1 is None: never written, never read)
+            raw2, out, bn2, wp2t = _conv_bn_relu(dt, raw1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf, lazy,
+                                                 in_bn=bn1)
+        else:
+            raw2, out, bn2, wp2t = _conv_bn_relu(dt, a1, None, w2, b2, g2, be2, rm2, rv2, nbt2, train, pool, grad, inf, lazy)
         if inf or not grad:
             return out, ()
-        ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt = bn1, bn2, train, pool, dt
+        ctx.bn1, ctx.bn2, ctx.train, ctx.pool, ctx.dt, ctx.on_load = bn1, bn2, train, pool, dt, on_load
         ctx.small = (b1, g1, be1, b2, g2, be2)  # leaf parameters: only their gradient destinations are needed
         return out, (x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t)
 
@@ -659,7 +676,12 @@ class ConvBlockFn(torch.autograd.Function):
         # ---- second conv layer
         draw2, dg2, dbe2, db2 = _bn_relu_bwd(dt, dout, raw2, ctx.bn2, train, pool, b2, g2, be2, reduced, dy2=dout2)
         dw2 = grad_out(w2)
-        if not pair:
+        if ctx.on_load:  # (a1 was never written: the weight gradient transforms raw1 on load)
+            slabs = _f32(L.wgrad_workspace_elems(L.CONV3, C, C, B, H, W), dev)
+            _timed("conv_wgrad<bf16,CONV3>(+reduce)", 2.0 * B * H * W * C * C * 9, L.conv_wgrad_bnrelu_p, dt, ptr(raw1), C,
+                   ptr(ctx.bn1.scale), ptr(ctx.bn1.shift), ptr(draw2), C, ptr(dw2), ptr(slabs), B, H, W, s,
+                   nbytes=B * H * W * 2 * C * _esz(dt) + 9 * C * C * 4)
+        elif not pair:
             _wgrad(dt, L.CONV3, a1, None, draw2, dw2, B, H, W)
         if wp2t is None:
             wp2t = _pack_conv(w2, dt, True)

@@ -30,8 +30,9 @@ MAP = {
     "hbm:bn_relu_apply": (r"bn_relu_apply_kernel", r"Lb0E"), "hbm:bn_relu_apply+pool": (r"bn_relu_apply_kernel", r"Lb1E"),
     "hbm:bn_bwd_reduce": (r"bn_bwd_reduce_kernel", r"Lb0ELb"), "hbm:bn_bwd_reduce+pool": (r"bn_bwd_reduce_kernel", r"Lb1ELb"),
     "hbm:bn_bwd_apply": (r"bn_bwd_apply_kernel", r"Lb0ELb"), "hbm:bn_bwd_apply+pool": (r"bn_bwd_apply_kernel", r"Lb1ELb"),
-    "hbm:stem_fwd": (r"stem_fwd_kernel",), "hbm:stem_bwd": (r"stem_bwd_kernel",), "hbm:head_fwd": (r"head_fwd_kernel",),
-    "hbm:head_bwd": (r"head_bwd_kernel",), "hbm:ce_fwd": (r"ce_fwd_kernel",), "hbm:ce_bwd": (r"ce_bwd_kernel",),
+    "hbm:stem_fwd": (r"stem_fwd_kernel",), "hbm:stem_bwd": (r"stem_bwd_kernel",), "hbm:head_fwd": (r"head_fwd_kernel", r"Lb0E"),
+    "hbm:head_bwd": (r"head_bwd_kernel", r"Lb0E"), "hbm:head_fwd+bn_relu": (r"head_fwd_kernel", r"Lb1E"),
+    "hbm:head_bwd+bn_bwd_sums": (r"head_bwd_kernel", r"Lb1E"), "hbm:ce_fwd": (r"ce_fwd_kernel",), "hbm:ce_bwd": (r"ce_bwd_kernel",),
     "hbm:bilinear_fwd": (r"bilinear_fwd_kernel",), "hbm:bilinear_bwd": (r"bilinear_bwd_kernel",),
     "hbm:adam_step": (r"adam_kernel",),
 }

@@ -164,7 +164,8 @@ def test_profile_records_carry_bytes_for_hbm_groups(hs):
     finally:
         ops.PROFILE = None
     keys = {r[0] for r in rec}
-    for k in ("hbm:bn_relu_apply", "hbm:bn_bwd_apply", "hbm:stem_fwd", "hbm:stem_bwd", "hbm:head_fwd", "hbm:head_bwd",
+    for k in ("hbm:bn_relu_apply", "hbm:bn_bwd_apply", "hbm:stem_fwd", "hbm:stem_bwd", "hbm:head_fwd+bn_relu",
+              "hbm:head_bwd+bn_bwd_sums",
               "hbm:ce_fwd", "hbm:ce_bwd", "hbm:bilinear_fwd"):
         assert k in keys, (k, sorted(keys))
     for key, flops, nbytes, e0, e1 in rec:
@@ -274,30 +275,32 @@ def test_wgrad_with_batchnorm_relu_on_load_is_bit_identical(hs, case):
 
 def test_convblock_with_batchnorm_on_load_equals_per_op_path(hs):
     """a full-resolution ConvBlockDownsample (32 -> 64 at 2 x 256 x 256: the block call applies the first BatchNorm + ReLU in
-    the second convolution's load path and never writes the intermediate) against the per-op path, which materialises it:
-    outputs, input gradient, every parameter gradient and the BatchNorm buffers bit for bit."""
+    the second convolution's load path and never writes the intermediate) against the per-op launch sequence, once with the
+    intermediate materialised and once through the same on-load kernels (what bench.py's profiling leg runs): outputs,
+    input gradient, every parameter gradient and the BatchNorm buffers bit for bit."""
     from models.processing_blocks import ConvBlockDownsample
 
     L, ops = hs.L, hs.ops
     assert L.conv3_bnrelu_in_applies(L.BF16, 64, 64, 2, 256, 256) and L.conv_wgrad_bnrelu_p_applies(L.BF16, 64, 64, 2, 256, 256)
     assert not L.conv_wgrad_pair_applies(L.BF16, 32, 0, 64, 64, 2, 256, 256)
     res = []
-    for per_op in (False, True):
+    for per_op in (0, 1, 2):
         torch.manual_seed(7)
         m = ConvBlockDownsample(32, 64).cuda().train()
         x = to_dev_nhwc(T("r4.blkol", (2, 32, 256, 256)), torch.bfloat16).requires_grad_(True)
-        old = ops._NO_BLOCK_CALLS
-        ops._NO_BLOCK_CALLS = per_op
+        old = ops._NO_BLOCK_CALLS, ops._PEROP_ON_LOAD
+        ops._NO_BLOCK_CALLS, ops._PEROP_ON_LOAD = bool(per_op), per_op != 1  # 1: materialising per-op path, 2: on-load per-op path
         try:
             with torch.autocast("cuda"):
                 y = m(x)
             y.float().square().mean().backward()
         finally:
-            ops._NO_BLOCK_CALLS = old
+            ops._NO_BLOCK_CALLS, ops._PEROP_ON_LOAD = old
         torch.cuda.synchronize()
         res.append([y.detach(), x.grad] + [p.grad.clone() for p in m.parameters()] + [b.clone() for b in m.buffers()])
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
 
 
 def test_hip_adam_through_gradscaler_with_its_own_inf_check(hs):
