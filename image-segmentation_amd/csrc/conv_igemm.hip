@@ -109,7 +109,11 @@ __device__ __forceinline__ constexpr int tap_off(int tap) {
 // instead turns its 32-pixel x (32*NTL)-channel sub-tile through a private LDS tile (fp32) and
 // writes full 16-byte channel vectors per lane: 128 contiguous bytes per pixel for a 64-channel wave tile.
 // Also adds the bias and reduces the BatchNorm partial statistics (sum, sum of squares per channel).
-template <typename T, int MODE, int BN, int NW, int THT = 16, bool AFF = false>
+// BWS (bf16, plain NHWC destination, gemm1_kernel's data gradient only: hipseg_convT_dgrad_bnstats): the output is dy of
+// relu(bn(xr)), xr = p.bw_x; the store loop -- where a lane holds 8 channels of a pixel -- also forms the BatchNorm-backward
+// sums [sum g | sum g * xhat] of its values (g = the bf16-rounded output where xr * scale + shift > 0), summed over the
+// workgroup into row `mtile` of p.stats (see conv3_m16.hip's EPI = 2 for the same epilogue on the 16x16x32 kernel).
+template <typename T, int MODE, int BN, int NW, int THT = 16, bool AFF = false, bool BWS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
                                               f32x16 (&acc)[WG<BN, NW, THT>::MT][WG<BN, NW, THT>::NTL],
                                               unsigned char* smem, int mtile, int img, int y0, int x0, int n0) {
@@ -117,6 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     constexpr int MT = WG<BN, NW, THT>::MT, NTL = WG<BN, NW, THT>::NTL;
     (void)WM;
     (void)mtile;
+    static_assert(!BWS || (MODE == HIPSEG_CONV1 && sizeof(T) == 2 && 32 * NTL == 64), "BatchNorm-backward epilogue: geometry");
     constexpr int TN = 32 * NTL;            // channels of the wave tile
     constexpr int VEC = VecOf<T>::N;        // channels per 16-byte store
     constexpr int VPR = TN / VEC;           // vectors per pixel row
@@ -160,6 +165,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     // vector path needs every 8(4)-channel group to stay inside one destination tensor / tap group
     const bool vec_ok = (p.N0 % VEC == 0) && (p.N1 % VEC == 0);
     const int nw0 = n0 + wn * (BN / WN);  // first channel of this wave's tile
+
+    // BWS: the lane's 8 channels are the same in every store iteration (64 % VPR == 0); all reads of xr go out now
+    float bmn[BWS ? 8 : 1], bis[BWS ? 8 : 1], bsc[BWS ? 8 : 1], bsh[BWS ? 8 : 1], bs1[BWS ? 8 : 1], bs2[BWS ? 8 : 1];
+    typename VecOf<T>::type bxr[BWS ? MT : 1][BWS ? NIT : 1];
+    if constexpr (BWS) {
+        const int n = nw0 + (lane % VPR) * VEC;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int nn = n + q < p.N ? n + q : p.N - 1;
+            bmn[q] = p.bw_bn[nn];
+            bis[q] = p.bw_bn[p.N + nn];
+            bsc[q] = p.bw_bn[2 * (size_t)p.N + nn];
+            bsh[q] = p.bw_bn[3 * (size_t)p.N + nn];
+            bs1[q] = 0.f;
+            bs2[q] = 0.f;
+        }
+        const T* rx = reinterpret_cast<const T*>(p.bw_x);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rr = (it * 64 + lane) / VPR;
+                const int y = y0 + 2 * (wm * MT + i) + (rr >> 4), x = x0 + sub_px<MODE>(rr);
+                const bool in = y < p.H && x < p.W && n < p.N;
+                const long opix = in ? ((long)img * p.H + y) * p.W + x : 0;
+                bxr[i][it] = *reinterpret_cast<const typename VecOf<T>::type*>(rx + opix * p.N + (in ? n : 0));
+            }
+    }
 
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -212,6 +245,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
                         dst = (n < p.N0) ? out0 + opix * p.N0 + n : out1 + opix * p.N1 + (n - p.N0);
                     }
                     *reinterpret_cast<typename VecOf<T>::type*>(dst) = o;
+                    if constexpr (BWS) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float xv = (float)bxr[i][it][q];
+                            const float gq = xv * bsc[q] + bsh[q] > 0.f ? (float)o[q] : 0.f;
+                            bs1[q] += gq;
+                            bs2[q] += gq * ((xv - bmn[q]) * bis[q]);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
@@ -236,6 +278,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (BWS) {
+        // lanes with the same channel vector (lane % 8), then the WM waves of a channel half through LDS (behind the
+        // waves' transpose tiles), in wave order
+        float* red = reinterpret_cast<float*>(smem) + NW * (32 * TN);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                bs1[q] += __shfl_xor(bs1[q], o, 64);
+                bs2[q] += __shfl_xor(bs2[q], o, 64);
+            }
+            if (lane < 8) {
+                red[(wave * 2 + 0) * 64 + lane * 8 + q] = bs1[q];
+                red[(wave * 2 + 1) * 64 + lane * 8 + q] = bs2[q];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * WN * 64; idx += NW * 64) {
+            const int arr = idx / (WN * 64), c = idx - arr * (WN * 64), wn_ = c / 64, cc = c - wn_ * 64;
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) t += red[((m * WN + wn_) * 2 + arr) * 64 + cc];
+            const int n = n0 + wn_ * (BN / WN) + cc;
+            if (n < p.N) p.stats[((size_t)mtile * 2 + arr) * p.N + n] = t;
+        }
+        return;
     }
     if (p.stats && !(p.debug & 32)) {
         // one statistics row per 64-row group (4 per tile): no cross-wave reduction, the finalize kernel sums rows
@@ -698,7 +767,7 @@ __global__ __launch_bounds__((64 * DmaWaves<BN, THT>::value), (DmaWaves<BN, THT>
 // touches fall on 16 different (bank half, slot) pairs: conflict-free fragment reads out of 128-byte rows.
 // Weights: [k-octet][n][8] packed operand, chunk read into VGPRs one stage ahead and written with ds_write_b128, as in
 // the ring kernels.  Needs C0 % 64 == 0 and N % 128 == 0 (every ConvT of the U-Nets but dec4's data gradient).
-template <int MODE>
+template <int MODE, bool BWS = false>
 __global__ __launch_bounds__(512, 1) void gemm1_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16 T;
@@ -839,7 +908,7 @@ __global__ __launch_bounds__(512, 1) void gemm1_kernel(ConvArgs p) {
         if (moreB) writeB(cur);
     }
     static_assert(NAW == KS, "one activation piece per k16 step");
-    conv_epilogue<bf16, EMODE, BN, NW, THT>(p, acc, smem, mtile, img, y0, x0, n0);
+    conv_epilogue<bf16, EMODE, BN, NW, THT, false, BWS>(p, acc, smem, mtile, img, y0, x0, n0);
 #else
     (void)p;
 #endif
@@ -1463,6 +1532,15 @@ int launch_gemm1(const ConvArgs& a0, hipStream_t s) {
     const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.ntn;
     static const bool no_xcd = getenv("HIPSEG_NO_XCD") != nullptr;
     a.xcd = (!no_xcd && grid % 8 == 0 && grid >= 64) ? (int)(grid / 8) : 0;
+    if constexpr (MODE == HIPSEG_CONV2S2) {
+        if (a.bw_x) {  // data gradient + BatchNorm-backward sums of its output (rows = pixel tiles)
+            HS_REQUIRE(a.stats && a.bw_bn && a.N0 % 8 == 0 && !a.N1, "conv_gemm1: BatchNorm-backward epilogue operands");
+            if (int rc = hs_set_max_lds(reinterpret_cast<const void*>(&gemm1_kernel<MODE, true>), (size_t)lds)) return rc;
+            hipLaunchKernelGGL((gemm1_kernel<MODE, true>), dim3((unsigned)grid), dim3(512), lds, s, a);
+            HS_LAUNCH_CHECK("conv_gemm1(bn sums)");
+            return HIPSEG_OK;
+        }
+    }
     hipLaunchKernelGGL((gemm1_kernel<MODE>), dim3((unsigned)grid), dim3(512), lds, s, a);
     HS_LAUNCH_CHECK("conv_gemm1");
     return HIPSEG_OK;
@@ -1580,6 +1658,27 @@ extern "C" int hipseg_conv_stats_rows(int dtype, int mode, int C0, int C1, int N
     return hipseg_conv_mtiles(B, H, W);
 }
 
+int convt_stream_bws_rows(int C0, int N, int B, int H, int W, int ncu);
+
+// Which kernel runs a ConvTranspose2d data gradient (mode CONV2S2: dy with C0 = Cout channels on the 2H x 2W grid -> dx
+// with N0 = Cin channels on H x W) WITH the BatchNorm-backward epilogue: 0 none, 1 the streaming kernel, 2 gemm1_kernel;
+// *rows = partial rows it writes.  Mirrors conv_igemm_impl's dispatch order for that mode.
+static int convt_dgrad_bws_kernel(int dtype, int C0, int N0, int B, int H, int W, int* rows) {
+    static const bool off = getenv("HIPSEG_NO_CONVT_DGRAD_BNSTATS") != nullptr || getenv("HIPSEG_NO_DMA") != nullptr ||
+                            getenv("HIPSEG_NO_GEMM1") != nullptr;  // A/B switches
+    *rows = 0;
+    if (off || dtype != HIPSEG_BF16 || N0 % 8) return 0;
+    if (convt_stream_applies(dtype, HIPSEG_CONV2S2, C0, 0, N0, 0, B, H, W)) {
+        *rows = convt_stream_bws_rows(C0, N0, B, H, W, device_cus());
+        return *rows ? 1 : 0;  // (the plain launch would take the streaming kernel too: no gemm1 fallback)
+    }
+    const size_t in_bytes = (size_t)B * 2 * H * 2 * W * (size_t)C0 * 2, w_bytes = (size_t)9 * hipseg_kpad(C0, dtype) * hipseg_npad(N0) * 2;
+    if (in_bytes > ((size_t)1 << 30) || w_bytes > ((size_t)1 << 30)) return 0;
+    if (C0 % 64 || hipseg_npad(N0) != N0 || N0 % 128 || hipseg_kpad(C0, dtype) != C0 || 4 * C0 < 256) return 0;
+    *rows = B * cdiv(W, TW) * cdiv(H, TH);
+    return 2;
+}
+
 static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const void* in1, int C1, const void* wp,
                            const float* bias, const float* post_scale, void* out0, int N0, void* out1, int N1,
                            float* stats, int B, int H, int W, hipseg_stream_t stream, const void* bw_x = nullptr,
@@ -1645,6 +1744,12 @@ static int conv_igemm_impl(int dtype, int mode, const void* in0, int C0, const v
         const size_t in_bytes = (size_t)B * a.Hi * a.Wi * (size_t)(C0 > C1 ? C0 : C1) * 2;
         const size_t w_bytes = (size_t)9 * a.Kp * a.Np * 2;
         const bool buf_ok = in_bytes <= ((size_t)1 << 30) && w_bytes <= ((size_t)1 << 30);
+        if (bw_x && mode == HIPSEG_CONV2S2) {  // (hipseg_convT_dgrad_bnstats checked the shape)
+            int rows;
+            const int k = convt_dgrad_bws_kernel(dtype, C0, N0, B, H, W, &rows);
+            HS_REQUIRE(k && !C1 && !N1 && !bias, "convT_dgrad_bnstats: no kernel with the BatchNorm-backward epilogue takes this shape");
+            return k == 1 ? convt_stream_launch(a, mode, s) : launch_gemm1<HIPSEG_CONV2S2>(a, s);
+        }
         if (bw_x) {  // (hipseg_conv3_dgrad_bnstats checked that the shape has a kernel with that epilogue)
             const int r16 = conv3_m16_rows(dtype, mode, C0, C1, N0, N1, B, H, W);
             HS_REQUIRE(r16 && !N1, "conv3_dgrad_bnstats: no kernel with the BatchNorm-backward epilogue takes this shape");
@@ -1723,6 +1828,25 @@ extern "C" int hipseg_conv3_dgrad_bnstats(int dtype, const void* dy, int C, cons
                "conv3_dgrad_bnstats: unsupported shape (ask hipseg_conv3_dgrad_bnstats_rows first)");
     return conv_igemm_impl(dtype, HIPSEG_CONV3, dy, C, nullptr, 0, wp, nullptr, nullptr, out, N, nullptr, 0, partial, B, H, W,
                            stream, x, bn);
+}
+
+// The same for the data gradient of ConvTranspose2d(k2, s2) (/root/reference/models/processing_blocks.py:102: its input is
+// the previous ConvBlock's activated output, so its data gradient is that block's dout): dx = CONV2S2(dy, wp) on the H x W
+// grid and, in the same kernel, the BatchNorm-backward rows [sum g | sum g * xhat] of dx against x = that block's second
+// pre-normalisation tensor (Cin channels, H x W) and its bn vectors.  rows() = 0: no kernel with the epilogue takes the shape.
+extern "C" int hipseg_convT_dgrad_bnstats_rows(int dtype, int Cout, int Cin, int B, int H, int W) {
+    int rows;
+    convt_dgrad_bws_kernel(dtype, Cout, Cin, B, H, W, &rows);
+    return rows;
+}
+
+extern "C" int hipseg_convT_dgrad_bnstats(int dtype, const void* dy, int Cout, const void* wp, void* dx, int Cin, const void* x,
+                                          const float* bn, float* partial, int B, int H, int W, hipseg_stream_t stream) {
+    HS_REQUIRE(x && bn && partial, "convT_dgrad_bnstats: null operand");
+    HS_REQUIRE(hipseg_convT_dgrad_bnstats_rows(dtype, Cout, Cin, B, H, W) > 0,
+               "convT_dgrad_bnstats: unsupported shape (ask hipseg_convT_dgrad_bnstats_rows first)");
+    return conv_igemm_impl(dtype, HIPSEG_CONV2S2, dy, Cout, nullptr, 0, wp, nullptr, nullptr, dx, Cin, nullptr, 0, partial, B, H,
+                           W, stream, x, bn);
 }
 
 // conv3x3 over relu(in * scale[c] + shift[c]) (zero-padded): the BatchNorm + ReLU of the PREVIOUS layer applied in this

@@ -20,7 +20,12 @@
 namespace {
 
 // KS = K / 32 MFMA steps; NG = 32-channel output groups per wave; U = pixel blocks in flight per wave
-template <int MODE, int KS, int NG, int U>
+// BWS (data gradient only, hipseg_convT_dgrad_bnstats): the output is dy of relu(bn(xr)) -- the ConvTranspose2d's input is
+// the previous ConvBlock's activated output (/root/reference/models/processing_blocks.py:102-109), xr = p.bw_x the
+// convolution output that BatchNorm normalised -- and the kernel also reduces that BatchNorm's backward sums,
+// [sum g | sum g * xhat] with g = round_bf16(out) where xr * scale + shift > 0 (bn_bwd_reduce_kernel's rule, bn.hip), one
+// row per workgroup into p.stats: the reduce launch that would re-read both tensors is not needed.
+template <int MODE, int KS, int NG, int U, bool BWS = false>
 __global__ __launch_bounds__(256) void convt_stream_kernel(ConvArgs p, int nsets, int npb, int pbw) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16 T;
@@ -70,12 +75,32 @@ __global__ __launch_bounds__(256) void convt_stream_kernel(ConvArgs p, int nsets
             bv[g][k] = (FWD && p.bias) ? p.bias[n % p.N0] : 0.f;
         }
 
+    // BWS: per-lane BatchNorm vectors of the lane's 8 channels of each group, and the running sums
+    float mn[BWS ? NG : 1][8], is[BWS ? NG : 1][8], s2[BWS ? NG : 1][8], sh[BWS ? NG : 1][8];
+    float sg[BWS ? NG : 1][8], sgx[BWS ? NG : 1][8];
+    if constexpr (BWS) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int n = (g0 + g) * 32 + lg * 8 + k;
+                mn[g][k] = p.bw_bn[n];
+                is[g][k] = p.bw_bn[p.N + n];
+                s2[g][k] = p.bw_bn[2 * (size_t)p.N + n];
+                sh[g][k] = p.bw_bn[3 * (size_t)p.N + n];
+                sg[g][k] = 0.f;
+                sgx[g][k] = 0.f;
+            }
+    }
+    const T* rx = reinterpret_cast<const T*>(p.bw_x);
+
     T* out = reinterpret_cast<T*>(p.out0);
     const int wblk = p.W / 16;  // 16-pixel blocks per image row (launch condition: W % 16 == 0)
     int pb = strip * pbw;
     const int pb_end = pb + pbw < npb ? pb + pbw : npb;
     for (; pb < pb_end; pb += U) {
         bf16x8 xb[U][KS];
+        bf16x8 xr[BWS ? U : 1][BWS ? NG : 1];
         int oy[U], ox[U], oimg[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -95,6 +120,11 @@ __global__ __launch_bounds__(256) void convt_stream_kernel(ConvArgs p, int nsets
                     off = (unsigned)(ipix * Cin_row * 2) + (unsigned)(c * 2 + lg * 16);
                 }
                 xb[u][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, 0));
+            }
+            if constexpr (BWS) {  // (tail blocks re-read the last block's pixels; their contribution is masked below)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    xr[u][g] = *reinterpret_cast<const bf16x8*>(rx + ((size_t)row * p.W + ox[u]) * p.N0 + (g0 + g) * 32 + lg * 8);
             }
         }
 #pragma unroll
@@ -130,8 +160,45 @@ __global__ __launch_bounds__(256) void convt_stream_kernel(ConvArgs p, int nsets
                         opix = ((size_t)oimg[u] * p.H + oy[u]) * p.W + ox[u];
                     }
                     *reinterpret_cast<bf16x8*>(out + opix * p.N0 + co) = o;
+                    if constexpr (BWS) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float xv = (float)xr[u][g][k];
+                            const float gq = xv * s2[g][k] + sh[g][k] > 0.f ? (float)o[k] : 0.f;
+                            sg[g][k] += gq;
+                            sgx[g][k] += gq * ((xv - mn[g][k]) * is[g][k]);
+                        }
+                    }
                 }
             }
+        }
+    }
+    if constexpr (BWS) {
+        // wave: the 16 pixels of a block sit in the 16 lanes li of a channel octet lg; workgroup: the waves whose channel
+        // set is the same (wave % nsets: launch condition 4 % nsets == 0) are summed in wave order through LDS
+        __shared__ float sm[4][2][NG * 32];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    sg[g][k] += __shfl_xor(sg[g][k], o, 64);
+                    sgx[g][k] += __shfl_xor(sgx[g][k], o, 64);
+                }
+                if (li == 0) {
+                    sm[wave][0][g * 32 + lg * 8 + k] = sg[g][k];
+                    sm[wave][1][g * 32 + lg * 8 + k] = sgx[g][k];
+                }
+            }
+        __syncthreads();
+        const int N = p.N;  // = nsets * NG * 32
+        for (int idx = threadIdx.x; idx < 2 * N; idx += 256) {
+            const int arr = idx / N, c = idx - arr * N;
+            const int set = c / (NG * 32), cl = c - set * (NG * 32);
+            float t = 0.f;
+            for (int w = set; w < 4; w += nsets) t += sm[w][arr][cl];
+            p.stats[((size_t)blockIdx.x * 2 + arr) * N + c] = t;
         }
     }
 #else
@@ -142,20 +209,44 @@ __global__ __launch_bounds__(256) void convt_stream_kernel(ConvArgs p, int nsets
 #endif
 }
 
+// strips of pixel blocks and workgroups of a launch (also the row count of the BatchNorm-backward epilogue)
+struct StreamGrid {
+    int nsets, npb, pbw;
+    long grid;
+};
+template <int NG, int U>
+StreamGrid stream_grid(int N, int B, int H, int W, int ncu, bool bws) {
+    StreamGrid g;
+    const int groups = N / 32;
+    g.nsets = groups / NG;
+    g.npb = (int)((long)B * H * W / 16);
+    // ~12 waves per CU: enough loads in flight, and a wave amortises its weight fragments over >= 8 pixel blocks
+    // (BatchNorm-backward epilogue: ~240 VGPRs, two waves per SIMD = 8 per CU)
+    long waves = (long)ncu * (bws ? 8 : 12);
+    long strips = waves / g.nsets;
+    if (strips < 1) strips = 1;
+    int pbw = (int)((g.npb + strips - 1) / strips);
+    if (pbw < 8) pbw = 8;
+    g.pbw = (pbw + U - 1) / U * U;
+    const long nstrips = (g.npb + g.pbw - 1) / g.pbw;
+    g.grid = (nstrips * g.nsets + 3) / 4;
+    return g;
+}
+
 template <int MODE, int KS, int NG, int U>
 int launch_stream(const ConvArgs& a, hipStream_t s) {
-    const int groups = a.N / 32, nsets = groups / NG;
-    const int npb = (int)((long)a.B * a.H * a.W / 16);
-    // ~12 waves per CU: enough loads in flight, and a wave amortises its weight fragments over >= 8 pixel blocks
-    long waves = (long)a.ncu * 12;
-    long strips = waves / nsets;
-    if (strips < 1) strips = 1;
-    int pbw = (int)((npb + strips - 1) / strips);
-    if (pbw < 8) pbw = 8;
-    pbw = (pbw + U - 1) / U * U;
-    const long nstrips = (npb + pbw - 1) / pbw;
-    const long grid = (nstrips * nsets + 3) / 4;
-    hipLaunchKernelGGL((convt_stream_kernel<MODE, KS, NG, U>), dim3((unsigned)grid), dim3(256), 0, s, a, nsets, npb, pbw);
+    const bool bws = MODE == HIPSEG_CONV2S2 && a.bw_x != nullptr;
+    const StreamGrid g = stream_grid<NG, U>(a.N, a.B, a.H, a.W, a.ncu, bws);
+    if constexpr (MODE == HIPSEG_CONV2S2) {
+        if (bws) {
+            HS_REQUIRE(4 % g.nsets == 0 && a.stats && a.bw_bn, "convt_stream: BatchNorm-backward epilogue operands");
+            hipLaunchKernelGGL((convt_stream_kernel<MODE, KS, NG, U, true>), dim3((unsigned)g.grid), dim3(256), 0, s, a, g.nsets,
+                               g.npb, g.pbw);
+            HS_LAUNCH_CHECK("convt_stream(bn sums)");
+            return HIPSEG_OK;
+        }
+    }
+    hipLaunchKernelGGL((convt_stream_kernel<MODE, KS, NG, U>), dim3((unsigned)g.grid), dim3(256), 0, s, a, g.nsets, g.npb, g.pbw);
     HS_LAUNCH_CHECK("convt_stream");
     return HIPSEG_OK;
 }
@@ -176,6 +267,14 @@ int convt_stream_applies(int dtype, int mode, int C0, int C1, int N0, int N1, in
     const size_t in_px = mode == HIPSEG_CONVT ? (size_t)B * H * W : (size_t)B * 4 * H * W;
     if (in_px * C0 * 2 > ((size_t)1 << 30)) return 0;
     return 1;
+}
+
+// rows the BatchNorm-backward epilogue of the data-gradient launch writes (0: the shape's set count does not divide the
+// four waves of a workgroup)
+int convt_stream_bws_rows(int C0, int N, int B, int H, int W, int ncu) {
+    const int K = 4 * C0;
+    const StreamGrid g = K == 64 ? stream_grid<2, 2>(N, B, H, W, ncu, true) : stream_grid<2, 2>(N, B, H, W, ncu, true);
+    return 4 % g.nsets == 0 ? (int)g.grid : 0;
 }
 
 int convt_stream_launch(const ConvArgs& a, int mode, hipStream_t s) {

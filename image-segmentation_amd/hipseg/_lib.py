@@ -46,6 +46,8 @@ PROTOTYPES = {
     "hipseg_stream_wait_event": (I, [P, P]),
     "hipseg_bucket_allreduce": (I, [P, c_size_t, I, P, P]),
     "hipseg_conv_affine_relu": (I, [I, P, I, P, I, P, P, P, P, I, I, I, I, P]),
+    "hipseg_convT_dgrad_bnstats_rows": (I, [I, I, I, I, I, I]),
+    "hipseg_convT_dgrad_bnstats": (I, [I, P, I, P, P, I, P, P, P, I, I, I, P]),
     "hipseg_conv3_bnrelu_in_applies": (I, [I, I, I, I, I, I]),
     "hipseg_conv3_bnrelu_in": (I, [I, P, I, P, P, P, P, P, I, P, I, I, I, P]),
     "hipseg_conv_wgrad_bnrelu_p_applies": (I, [I, I, I, I, I, I]),
@@ -114,7 +116,7 @@ class ConvBlockArgs(ctypes.Structure):
                 + [("dout_rows", ctypes.c_int32)])
 
 # functions whose int return value is a geometry answer, not a status code
-_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_conv3_bnrelu_in_applies",
+_PURE = {"hipseg_abi_version", "hipseg_kpad", "hipseg_npad", "hipseg_conv_mtiles", "hipseg_conv_stats_rows", "hipseg_conv3_dgrad_bnstats_rows", "hipseg_convT_dgrad_bnstats_rows", "hipseg_conv_wgrad_pair_applies", "hipseg_conv3_bnrelu_in_applies",
          "hipseg_conv_wgrad_bnrelu_p_applies", "hipseg_bn_bwd_blocks",
          "hipseg_colsum_blocks", "hipseg_stem_bwd_blocks", "hipseg_head_bwd_blocks", "hipseg_loss_blocks",
          "hipseg_wgrad_workspace_elems", "hipseg_convT_wgrad_workspace_elems", "hipseg_last_error", "hipseg_pack_desc_size", "hipseg_augment_workspace_elems", "hipseg_adam_desc_size",

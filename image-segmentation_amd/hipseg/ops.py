@@ -470,12 +470,14 @@ def _block_forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, 
     return out, ()
 
 
-def _block_partial_rows(dt, B, C, H, W, pool):
+def _block_partial_rows(dt, B, C, H, W, pool, up_cout=0):
     """rows of BatchNorm-backward partial sums a block's backward may see: the reduce kernels' blocks, the tiles of the
-    data-gradient kernel that reduces the first layer's sums in its epilogue (hipseg_conv3_dgrad_bnstats), or the blocks
-    of the head kernel that reduces the second layer's (hipseg_head_bwd_bnrelu)."""
+    data-gradient kernel that reduces the first layer's sums in its epilogue (hipseg_conv3_dgrad_bnstats), the blocks
+    of the head kernel that reduces the second layer's (hipseg_head_bwd_bnrelu), or the rows of the data gradient of a
+    ConvTranspose2d with `up_cout` output channels that consumes the block's output (hipseg_convT_dgrad_bnstats)."""
     return max(L.bn_bwd_blocks(B, H, W, C, dt, int(pool)), L.bn_bwd_blocks(B, H, W, C, dt, 0),
-               L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W), L.head_bwd_blocks(B, H, W))
+               L.conv3_dgrad_bnstats_rows(dt, C, C, B, H, W), L.head_bwd_blocks(B, H, W),
+               L.convT_dgrad_bnstats_rows(dt, up_cout, C, B, H, W) if up_cout else 0)
 
 
 def _block_backward(ctx, dout, dout2=None, reduced=None):
@@ -519,6 +521,8 @@ def _block_backward(ctx, dout, dout2=None, reduced=None):
 # A/B switch (read by models/processing_blocks.py): last ConvBlock and 1x1 head as two autograd nodes, with the BN-apply,
 # head and BN-backward reduce launches each on their own
 _NO_HEAD_FUSE = bool(os.environ.get("HIPSEG_NO_HEAD_FUSE"))
+# likewise: a ConvBlock and the ConvTranspose2d that consumes its output as two nodes (plain data gradient + reduce launch)
+_NO_UP_FUSE = bool(os.environ.get("HIPSEG_NO_UP_FUSE"))
 
 
 def _head_fwd(dt, x, w, b, bn=None):
@@ -556,6 +560,45 @@ def _head_bwd(dt, x, dl, w, bias, bn=None, bn_partial=None):
     return dx, dw, db
 
 
+def _convT_fwd(dt, x, w, b):
+    """nn.ConvTranspose2d(Cin, Cout, 2, stride=2) on NHWC activations"""
+    B, cin, H, W = x.shape
+    cout = w.shape[1]
+    y = nhwc_empty(B, cout, 2 * H, 2 * W, x.dtype, x.device)
+    igemm(dt, L.CONVT, x, cin, None, 0, _pack_convT(w, dt, False), b, y, cout, None, 0, None, B, H, W)
+    return y
+
+
+def _convT_bwd(dt, x, w, bias, dy, need_dx, bn_x=None, bn=None, partial=None):
+    """(dx, dw, db, rows) of the ConvTranspose2d.  `bn_x`, `bn` = (mean, invstd, scale, shift), `partial`: x is
+    relu(bn(bn_x)) of a train- or eval-mode BatchNorm whose backward comes next -- where a kernel with that epilogue takes
+    the shape the data gradient also leaves `rows` rows of its sums in `partial` (hipseg_convT_dgrad_bnstats), else 0."""
+    B, cin, H, W = x.shape
+    cout = w.shape[1]
+    dev = x.device
+    s = _stream()
+    dy = as_nhwc(dy, x.dtype)
+    dw, db = grad_out(w), grad_out(bias)
+    # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY fragments its MFMAs
+    # hold): dY is read once, one reduction launch writes both parameters' layouts
+    work = _f32(L.convT_wgrad_workspace_elems(cin, cout, B, H, W), dev)
+    key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},CONVT>(+bias,+reduce)"
+    _timed(key, 2.0 * B * H * W * 4 * cout * cin, L.convT_wgrad_bias, dt, ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(work), B,
+           H, W, cin, cout, s, nbytes=float(B * H * W) * (4 * cout + cin) * _esz(dt))
+    dx, rows = None, 0
+    if need_dx:
+        wpt = _pack_convT(w, dt, True)
+        dx = nhwc_empty(B, cin, H, W, x.dtype, dev)
+        rows = L.convT_dgrad_bnstats_rows(dt, cout, cin, B, H, W) if bn is not None else 0
+        if rows:
+            _timed(f"conv_igemm<bf16,CONV2S2,BN{128 if cin > 64 else 64}>+bn_bwd_sums", 2.0 * B * H * W * 4 * cout * cin,
+                   L.convT_dgrad_bnstats, dt, ptr(dy), cout, ptr(wpt), ptr(dx), cin, ptr(bn_x), ptr(bn[0]), ptr(partial), B, H, W,
+                   s, nbytes=float(B * H * W) * (4 * cout + 2 * cin) * _esz(dt))
+        else:
+            igemm(dt, L.CONV2S2, dy, cout, None, 0, wpt, None, dx, cin, None, 0, None, B, H, W)
+    return dx, dw, db, rows
+
+
 class ConvBlockFn(torch.autograd.Function):
     """[cat(x0,x1)] -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU [-> MaxPool2d(2,2)]
     = ConvBlock / ConvBlockDownsample / the conv half of ConvBlockUpsampleSkip
@@ -568,22 +611,31 @@ class ConvBlockFn(torch.autograd.Function):
     the function then returns the head's NCHW fp32 logits.  In train mode the block's last BatchNorm + ReLU is applied
     in the head's load path and the head's backward leaves that layer's BatchNorm-backward sums behind
     (hipseg_head_fwd_bnrelu / hipseg_head_bwd_bnrelu): two full-resolution passes fewer; otherwise block and head simply
-    run one after the other."""
+    run one after the other.
+    `uw`, `ub`: weight and bias of the ConvTranspose2d(k2, s2) that consumes the block's output (models/UNet.py:66-71,
+    processing_blocks.py:102: bottleneck -> dec1.up, dec_k.conv -> dec_k+1.up); the function then returns the up-sampled
+    tensor, and the ConvTranspose2d's data gradient -- which IS this block's dout -- also reduces the second layer's
+    BatchNorm-backward sums where a kernel with that epilogue takes the shape (hipseg_convT_dgrad_bnstats)."""
 
     @staticmethod
     def forward(ctx, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, train, pool,
-                no_grad=False, two=False, hw=None, hb=None):
+                no_grad=False, two=False, hw=None, hb=None, uw=None, ub=None):
         dt = _dt(x0)
         # (grad mode is off inside Function.forward, and needs_input_grad stays True for parameters under
         # torch.no_grad(): the caller passes whether a graph is being recorded at all)
         grad = any(ctx.needs_input_grad) and not no_grad
-        head = hw is not None
-        if head and (two or pool):
-            raise ValueError("ConvBlockFn: a head consumes the un-pooled output of a block with one consumer")
+        head, up = hw is not None, uw is not None
+        if (head or up) and (two or pool or (head and up)):
+            raise ValueError("ConvBlockFn: a head / ConvTranspose2d tail consumes the un-pooled output of a block with one consumer")
         lazy = head and grad and train
         out, saved = ConvBlockFn._forward(ctx, dt, x0, x1, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2,
                                           train, pool, grad, lazy)
-        ctx.head = ctx.lazy = False
+        ctx.head = ctx.lazy = ctx.up = False
+        if up:
+            y = _convT_fwd(dt, out, uw, ub)
+            if grad:
+                ctx.up, ctx.ubias, ctx.nsaved = True, ub, len(saved)
+                saved = saved + (uw, out)
         if head:
             if lazy:  # saved[6] = raw2; scale / shift of its BatchNorm from this forward's statistics
                 logits = _head_fwd(dt, saved[6], hw, hb, ConvBlockFn._bn2(ctx, saved))
@@ -594,6 +646,8 @@ class ConvBlockFn(torch.autograd.Function):
                 saved = saved + (hw,) + (() if lazy else (out,))
         if grad:
             ctx.save_for_backward(*saved)
+        if up:
+            return y
         if head:
             return logits
         if two:
@@ -641,9 +695,20 @@ class ConvBlockFn(torch.autograd.Function):
         if dout is None:
             dout, dout2 = dout2, None
         if dout is None:
-            return (None,) * 22
+            return (None,) * 24
         tail = (None,) * 10
         reduced = None
+        up_grads = (None, None)
+        if ctx.up:  # dout = d(up-sampled tensor): through the ConvTranspose2d first
+            saved = ctx.saved_tensors
+            uw, out = saved[ctx.nsaved], saved[ctx.nsaved + 1]
+            raw2 = saved[6]
+            B, C, H, W = raw2.shape
+            partial = _f32(_block_partial_rows(ctx.dt, B, C, H, W, False, uw.shape[1]) * 2 * C, raw2.device)
+            dout, duw, dub, rows = _convT_bwd(ctx.dt, out, uw, ctx.ubias, dout, True, raw2, ConvBlockFn._bn2(ctx, saved), partial)
+            if rows:
+                reduced = (partial, rows)
+            up_grads = (duw, dub)
         if ctx.head:  # dout = d(logits): through the head first
             saved = ctx.saved_tensors
             hw = saved[ctx.nsaved]
@@ -658,6 +723,7 @@ class ConvBlockFn(torch.autograd.Function):
             tail = tail + (dhw, dhb)
         else:
             tail = tail + (None, None)
+        tail = tail + up_grads
         if ctx.blk is not None:
             return _block_backward(ctx, dout, dout2, reduced) + tail
         x0, x1, w1, w2, raw1, a1, raw2, wp1t, wp2t = ctx.saved_tensors[:9]
@@ -728,11 +794,7 @@ class ConvT2x2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         dt = _dt(x)
-        B, cin, H, W = x.shape
-        cout = w.shape[1]
-        wp = _pack_convT(w, dt, False)
-        y = nhwc_empty(B, cout, 2 * H, 2 * W, x.dtype, x.device)
-        igemm(dt, L.CONVT, x, cin, None, 0, wp, b, y, cout, None, 0, None, B, H, W)
+        y = _convT_fwd(dt, x, w, b)
         ctx.save_for_backward(x, w)
         ctx.dt, ctx.bias = dt, b
         return y
@@ -740,24 +802,7 @@ class ConvT2x2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dt = ctx.dt
-        B, cin, H, W = x.shape
-        cout = w.shape[1]
-        dev = x.device
-        s = _stream()
-        dy = as_nhwc(dy, x.dtype)
-        dw, db = grad_out(w), grad_out(ctx.bias)
-        # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY fragments its MFMAs
-        # hold): dY is read once, one reduction launch writes both parameters' layouts
-        work = _f32(L.convT_wgrad_workspace_elems(cin, cout, B, H, W), dev)
-        key = f"conv_wgrad<{'bf16' if dt == L.BF16 else 'f32'},CONVT>(+bias,+reduce)"
-        _timed(key, 2.0 * B * H * W * 4 * cout * cin, L.convT_wgrad_bias, dt, ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(work), B,
-               H, W, cin, cout, s, nbytes=float(B * H * W) * (4 * cout + cin) * _esz(dt))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wpt = _pack_convT(w, dt, True)
-            dx = nhwc_empty(B, cin, H, W, x.dtype, dev)
-            igemm(dt, L.CONV2S2, dy, cout, None, 0, wpt, None, dx, cin, None, 0, None, B, H, W)
+        dx, dw, db, _ = _convT_bwd(ctx.dt, x, w, ctx.bias, dy, ctx.needs_input_grad[0])
         return dx, dw, db
 
 

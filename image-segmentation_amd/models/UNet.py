@@ -59,11 +59,16 @@ class _UNetBase(nn.Module):
             else:
                 h, h_skip = enc.forward_two(h)
             skips.append(h_skip)
-        h = self.bottleneck(h) if fuse is None else fuse(h, skips)
-        last = len(self._dec)
-        for k in range(1, last):
-            h = getattr(self, f"dec{k}")(h, skips[-k])
-        return getattr(self, f"dec{last}").forward_head(h, skips[-last], self.out)  # last block + 1x1 head: one node
+        # each ConvBlock runs as ONE autograd node with the consumer of its output -- the next decoder block's
+        # ConvTranspose2d, or the 1x1 head after the last block (ops.ConvBlockFn): u = the up-sampled tensor handed on
+        decs = [getattr(self, f"dec{k}") for k in range(1, len(self._dec) + 1)]
+        if fuse is None:
+            u = self.bottleneck.forward_up(h, decs[0].up)
+        else:
+            u = decs[0].up_only(fuse(h, skips))
+        for k, dec in enumerate(decs[:-1]):
+            u = dec.forward_from_up(u, skips[-(k + 1)], next_up=decs[k + 1].up)
+        return decs[-1].forward_from_up(u, skips[-len(decs)], head=self.out)
 
     @torch.compiler.disable
     def forward(self, x):

@@ -17,10 +17,11 @@ from hipseg import ops
 
 
 
-def _double_conv(seq, x, skip, pool, two=False, head=None):
+def _double_conv(seq, x, skip, pool, two=False, head=None, up=None):
     """seq = (conv, bn, relu, conv, bn, relu) parameter container of one ConvBlock.
     two: (output, alias of the output) for a block whose output has two consumers (see ops.ConvBlockFn).
-    head: the 1x1 nn.Conv2d that consumes the block's output; its NCHW fp32 logits are returned instead."""
+    head: the 1x1 nn.Conv2d that consumes the block's output; its NCHW fp32 logits are returned instead.
+    up: the nn.ConvTranspose2d(k2, s2) that consumes the block's output; the up-sampled tensor is returned instead."""
     c1, n1, _, c2, n2, _ = seq
     td = ops._tdtype(ops.precision())
     x = ops.as_nhwc(x, td)
@@ -34,6 +35,12 @@ def _double_conv(seq, x, skip, pool, two=False, head=None):
     train = n1.training
     stats = (n1.running_mean, n1.running_var, n1.num_batches_tracked, n2.running_mean, n2.running_var,
              n2.num_batches_tracked)
+    if up is not None:
+        if up.kernel_size != (2, 2) or up.stride != (2, 2) or up.in_channels != c2.out_channels or head is not None:
+            raise ValueError(f"up must be a ConvTranspose2d(k2, s2) over {c2.out_channels} channels")
+        return ops.ConvBlockFn.apply(x, skip, c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight,
+                                     n2.bias, *stats, train, pool, not torch.is_grad_enabled(), two, None, None, up.weight,
+                                     up.bias)
     if head is not None:
         if head.kernel_size != (1, 1) or head.in_channels != c2.out_channels:
             raise ValueError(f"head must be a 1x1 convolution over {c2.out_channels} channels")
@@ -60,6 +67,16 @@ class ConvBlock(nn.Module):
     @torch.compiler.disable
     def forward(self, x):
         return _double_conv(self.conv, x, None, False)
+
+    @torch.compiler.disable
+    def forward_up(self, x, up):
+        """up(self(x)) for the ConvTranspose2d(k2, s2) `up` that consumes this block's output (reference:
+        models/UNet.py:66-67, bottleneck -> dec1.up) as ONE autograd node: the ConvTranspose2d's data gradient is this
+        block's output gradient and, where the shape has such a kernel, also reduces the BatchNorm-backward sums of the
+        block's last layer (ops.ConvBlockFn)."""
+        if ops._NO_UP_FUSE:
+            return _upsample(up, self.forward(x))
+        return _double_conv(self.conv, x, None, False, up=up)
 
 
 class ConvBlockDownsample(nn.Module):
@@ -99,10 +116,26 @@ class ConvBlockUpsampleSkip(nn.Module):
 
     @torch.compiler.disable
     def forward(self, x, skip):
-        x = _upsample(self.up, x)
-        if x.shape[2:] != skip.shape[2:]:
-            x = ops.BilinearFn.apply(x, skip.shape[2], skip.shape[3])
-        return _double_conv(self.conv.conv, x, skip, False)
+        return self.forward_from_up(_upsample(self.up, x), skip)
+
+    @torch.compiler.disable
+    def up_only(self, x):
+        """self.up(x): the first half of forward(), for callers that hand the result to forward_from_up()"""
+        return _upsample(self.up, x)
+
+    @torch.compiler.disable
+    def forward_from_up(self, u, skip, next_up=None, head=None):
+        """the block behind `self.up`: u = self.up(x) (already computed, e.g. by the previous block's node) -> bilinear
+        resize to the skip's size -> cat -> ConvBlock.  `next_up` / `head`: the ConvTranspose2d of the NEXT decoder block /
+        the 1x1 output convolution that consumes this block's output (reference: models/UNet.py:68-73); the block and that
+        consumer then run as one autograd node (see ops.ConvBlockFn) and the consumer's result is returned."""
+        if u.shape[2:] != skip.shape[2:]:
+            u = ops.BilinearFn.apply(u, skip.shape[2], skip.shape[3])
+        if head is not None and ops._NO_HEAD_FUSE:  # A/B switch: two autograd nodes, every launch on its own
+            return ops.HeadFn.apply(_double_conv(self.conv.conv, u, skip, False), head.weight, head.bias)
+        if next_up is not None and ops._NO_UP_FUSE:
+            return _upsample(next_up, _double_conv(self.conv.conv, u, skip, False))
+        return _double_conv(self.conv.conv, u, skip, False, head=head, up=next_up)
 
     @torch.compiler.disable
     def forward_head(self, x, skip, head):
@@ -110,12 +143,7 @@ class ConvBlockUpsampleSkip(nn.Module):
         models/UNet.py:72-73), as NCHW fp32 logits.  One autograd node: in training the block's final BatchNorm + ReLU
         runs in the head kernel's load path and the head's backward reduces that layer's BatchNorm-backward sums
         (see ops.ConvBlockFn)."""
-        if ops._NO_HEAD_FUSE:  # A/B switch: two autograd nodes, every launch on its own
-            return ops.HeadFn.apply(self.forward(x, skip), head.weight, head.bias)
-        x = _upsample(self.up, x)
-        if x.shape[2:] != skip.shape[2:]:
-            x = ops.BilinearFn.apply(x, skip.shape[2], skip.shape[3])
-        return _double_conv(self.conv.conv, x, skip, False, head=head)
+        return self.forward_from_up(_upsample(self.up, x), skip, head=head)
 
 
 class ConvBlockUpsample(nn.Module):

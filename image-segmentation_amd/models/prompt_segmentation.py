@@ -79,7 +79,8 @@ class ClipUnetPrompt(nn.Module):
         attention_output = ops.as_nhwc(_fuse_clip(self, enc3, clip_features), prompt_embedding.dtype)
         # prompt_fusion(cat([attention_output, prompt_embedding], dim=1)): dual-source 1x1 conv, no concatenation
         fused = ops.Conv1x1Fn.apply(attention_output, prompt_embedding, self.prompt_fusion.weight, self.prompt_fusion.bias)
-        d = self.dec1(fused, enc3)
-        d = self.dec2(d, enc2)
-        d = self.dec3(d, enc1)
-        return self.activation(self.dec4.forward_head(d, inp_skip, self.out))  # last block + 1x1 head: one autograd node
+        # each decoder ConvBlock as one autograd node with the consumer of its output (next block's ConvTranspose2d / head)
+        u = self.dec1.forward_from_up(self.dec1.up_only(fused), enc3, next_up=self.dec2.up)
+        u = self.dec2.forward_from_up(u, enc2, next_up=self.dec3.up)
+        u = self.dec3.forward_from_up(u, enc1, next_up=self.dec4.up)
+        return self.activation(self.dec4.forward_from_up(u, inp_skip, head=self.out))

@@ -124,6 +124,18 @@ int hipseg_conv_affine_relu(int dtype, const void* in0, int C0, const void* in1,
                             const float* scale, const float* shift, void* out, int N, int B, int H, int W,
                             hipseg_stream_t stream);
 
+/* Data gradient of ConvTranspose2d(k2, s2) (processing_blocks.py:102,106: `self.up`) + the BatchNorm-backward sums of its
+ * output, in one kernel.  The ConvTranspose2d's input is the previous ConvBlock's activated output (models/UNet.py:66-71:
+ * bottleneck -> dec1.up, dec_k.conv -> dec_k+1.up), so dx IS that block's dout: dx = CONV2S2(dy (Cout, 2H x 2W), wp = the
+ * data-gradient operand of hipseg_pack_convT) on the H x W grid, and partial receives hipseg_convT_dgrad_bnstats_rows()
+ * rows of [2][Cin] floats = [sum g | sum g * xhat], g = dx where x * scale + shift > 0 (x = that block's second
+ * pre-normalisation tensor, bn = its [mean | invstd | scale | shift] vectors) -- the rows hipseg_bn_bwd_reduce would
+ * produce from a second pass over dx and x (hipseg_convblock_t::dout_rows).  rows() == 0: no kernel with that epilogue
+ * takes the shape (use hipseg_conv_igemm in mode HIPSEG_CONV2S2 + hipseg_bn_bwd_reduce). */
+int hipseg_convT_dgrad_bnstats_rows(int dtype, int Cout, int Cin, int B, int H, int W);
+int hipseg_convT_dgrad_bnstats(int dtype, const void* dy, int Cout, const void* wp, void* dx, int Cin, const void* x,
+                               const float* bn, float* partial, int B, int H, int W, hipseg_stream_t stream);
+
 /* ---- BatchNorm + ReLU applied in the CONSUMER's load path (round 4) ------------------------------
  * The second convolution of a ConvBlock reads relu(bn(raw1)); at the full-resolution levels (<= 64 channels) writing that
  * activated tensor and reading it back (hipseg_bn_relu_apply: 2 x 134 MB at 64 channels x 16 x 256 x 256) costs more

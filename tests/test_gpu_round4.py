@@ -552,3 +552,118 @@ def test_unet_head_node_in_eval_and_no_grad_modes(hs):
     assert torch.equal(res[0], a) and a.dtype == torch.float32 and a.shape == (2, 3, 32, 48)
     # (without a graph the eval-mode blocks run as fused conv + folded-BatchNorm + ReLU kernels: same values to bf16 rounding)
     assert (a - b.detach()).abs().max() <= 2e-2 * max(1.0, float(a.abs().max()))
+
+
+CONVT_DGRAD_BWS_CASES = [  # B, Cout (channels of dy), Cin (channels of dx), H, W of dx
+    (4, 32, 64, 32, 32),     # streaming kernel, one channel set per wave (dec4.up of the U-Nets)
+    (2, 32, 128, 16, 48),    # streaming kernel, two channel sets
+    (2, 32, 256, 16, 16),    # streaming kernel, four channel sets
+    (2, 64, 128, 32, 32),    # one-tap GEMM kernel (dec3.up)
+    (2, 128, 256, 16, 16),   # dec2.up
+    (1, 256, 512, 16, 32),   # dec1.up, four column tiles
+    (2, 64, 128, 24, 40),    # ragged pixel tiles
+]
+
+
+@pytest.mark.parametrize("case", CONVT_DGRAD_BWS_CASES, ids=str)
+def test_convT_data_gradient_with_batchnorm_backward_sums(hs, case):
+    """hipseg_convT_dgrad_bnstats == hipseg_conv_igemm(CONV2S2) bit for bit, and its rows finalize to the sums
+    hipseg_bn_bwd_reduce computes from the stored dx (another partition of the same fp32 sum)."""
+    L, ops = hs.L, hs.ops
+    B, CO, CI, H, W = case
+    td, dt = torch.bfloat16, L.BF16
+    rows = L.convT_dgrad_bnstats_rows(dt, CO, CI, B, H, W)
+    assert rows > 0
+    dy = to_dev_nhwc(rnd(T("r4.td.dy", (B, CO, 2 * H, 2 * W), -1, 1), td), td)
+    w = T("r4.td.w", (CI, CO, 2, 2), -0.4, 0.4).cuda()
+    raw = to_dev_nhwc(rnd(T("r4.td.raw", (B, CI, H, W), -2, 2), td), td)
+    mean = T("r4.td.mean", (CI,), -0.3, 0.3)
+    invstd = T("r4.td.is", (CI,), 0.5, 1.5)
+    gamma = T("r4.td.g", (CI,), -1.2, 1.2)
+    beta = T("r4.td.b", (CI,), -0.4, 0.4)
+    scale = gamma * invstd
+    bn = torch.cat([mean, invstd, scale, beta - mean * scale]).cuda().contiguous()
+    wpt = ops._pack_convT(w, dt, True)
+    s, p = ops._stream(), ops.ptr
+    ref = ops.nhwc_empty(B, CI, H, W, td, "cuda")
+    L.conv_igemm(dt, L.CONV2S2, p(dy), CO, 0, 0, p(wpt), 0, p(ref), CI, 0, 0, 0, B, H, W, s)
+    nred = L.bn_bwd_blocks(B, H, W, CI, dt, 0)
+    rows_ref = torch.zeros(nred, 2, CI, device="cuda")
+    L.bn_bwd_reduce2(dt, p(ref), 0, p(raw), p(bn), p(bn[CI:]), p(bn[2 * CI:]), p(bn[3 * CI:]), p(rows_ref), B, H, W, CI, 0, s)
+    sums_ref = torch.zeros(2 * CI, device="cuda")
+    L.colsum_finalize(p(rows_ref), nred, 2, CI, p(sums_ref), 0, s)
+    dx = ops.nhwc_empty(B, CI, H, W, td, "cuda")
+    part = torch.full((rows, 2, CI), float("nan"), device="cuda")
+    L.convT_dgrad_bnstats(dt, p(dy), CO, p(wpt), p(dx), CI, p(raw), p(bn), p(part), B, H, W, s)
+    sums = torch.zeros(2 * CI, device="cuda")
+    L.colsum_finalize(p(part), rows, 2, CI, p(sums), 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, ref) and float(dx.float().abs().max()) > 0
+    assert torch.isfinite(part).all()
+    err = (sums.double() - sums_ref.double()).abs().max()
+    assert err <= 1e-6 * max(1.0, float(sums_ref.abs().max())) * (B * H * W) ** 0.5 + 1e-4, float(err)
+    assert float(sums_ref.abs().max()) > 0
+
+
+def test_convT_data_gradient_with_sums_refuses_other_shapes(hs):
+    L = hs.L
+    assert L.convT_dgrad_bnstats_rows(L.BF16, 32, 96, 2, 16, 16) == 0     # three channel sets: not a divisor of 4 waves
+    assert L.convT_dgrad_bnstats_rows(L.BF16, 64, 64, 2, 16, 16) == 0     # GEMM kernel needs 128-channel column tiles
+    assert L.convT_dgrad_bnstats_rows(L.F32, 64, 128, 2, 16, 16) == 0     # bf16 kernels only
+    x = torch.zeros(8, device="cuda")
+    with pytest.raises(L.HipsegError):
+        L.convT_dgrad_bnstats(L.BF16, x.data_ptr(), 64, x.data_ptr(), x.data_ptr(), 64, x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                              2, 16, 16, hs.ops._stream())
+
+
+def _unet_step_with_up(hs, fuse, prec, per_op=False, model="UNet"):
+    import models.UNet as un
+    from models.losses import HybridLoss
+
+    ops = hs.ops
+    torch.manual_seed(17)
+    m = getattr(un, model)().cuda().train()
+    g = torch.Generator().manual_seed(19)
+    hw = (64, 96) if model == "UNet" else (64, 64)
+    x = torch.rand(2, 3, *hw, generator=g).cuda()
+    t = torch.randint(0, 3, (2, *hw), generator=g).cuda()
+    old = ops._NO_UP_FUSE, ops._NO_BLOCK_CALLS
+    ops._NO_UP_FUSE, ops._NO_BLOCK_CALLS = not fuse, per_op
+    try:
+        with ops.precision_mode(prec):
+            out = m(x)
+            loss = HybridLoss()(out, t)
+        loss.backward()
+    finally:
+        ops._NO_UP_FUSE, ops._NO_BLOCK_CALLS = old
+    torch.cuda.synchronize()
+    return out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}
+
+
+@pytest.mark.parametrize("prec,model", [("bf16", "UNet"), ("fp32", "UNet"), ("bf16", "LargeUNet")])
+def test_unet_block_and_following_convtranspose_as_one_node(hs, prec, model):
+    """models/UNet.py:66-71: every decoder ConvBlock (and the bottleneck) feeds exactly one ConvTranspose2d.  As one autograd
+    node the forward launches are the same (logits and BatchNorm buffers bit-identical); in backward the ConvTranspose2d's
+    data gradient also reduces the block's BatchNorm-backward sums, so the ConvTranspose2d's own gradients stay bit-identical
+    and everything behind the re-partitioned fp32 sums is compared to rounding / the storage precision."""
+    o0, g0, b0 = _unet_step_with_up(hs, False, prec, model=model)
+    o1, g1, b1 = _unet_step_with_up(hs, True, prec, model=model)
+    assert torch.equal(o0, o1)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    last = max(int(k[3]) for k in g0 if k.startswith("dec"))
+    for k in (f"dec{last}.up.weight", f"dec{last}.up.bias", "out.weight", "out.bias"):
+        assert torch.equal(g0[k], g1[k]), k
+    rel = 2e-5 if prec == "fp32" else 2e-2
+    for k in g0:
+        d = float((g0[k].double() - g1[k].double()).norm())
+        n = float(g0[k].double().norm())
+        if k.endswith(".bias") and k[:-4] + "weight" in g0:
+            # (a bias in front of a BatchNorm has a gradient that is a sum of cancelling terms -- exactly zero in exact
+            # arithmetic for the conv biases, border effects only for the stem's: scale by the module's weight gradient)
+            n = max(n, float(g0[k[:-4] + "weight"].double().norm()))
+        assert d <= rel * max(n, 1e-6), (k, d, n)
+    o2, g2, _ = _unet_step_with_up(hs, True, prec, per_op=True, model=model)
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
