@@ -27,6 +27,17 @@ def _head(conv, x):
     return ops.HeadFn.apply(x, conv.weight, conv.bias)
 
 
+def _hooked(*mods):
+    """True if a forward / backward hook is registered on one of the modules (or globally): the fused nodes below call
+    forward_from_up / forward_up instead of Module.__call__, which is where hooks fire -- such a model takes the plain
+    module-by-module path"""
+    import torch.nn.modules.module as M
+
+    if M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or M._global_backward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in mods)
+
+
 class _UNetBase(nn.Module):
     _enc = ()
     _bott = ()
@@ -62,6 +73,11 @@ class _UNetBase(nn.Module):
         # each ConvBlock runs as ONE autograd node with the consumer of its output -- the next decoder block's
         # ConvTranspose2d, or the 1x1 head after the last block (ops.ConvBlockFn): u = the up-sampled tensor handed on
         decs = [getattr(self, f"dec{k}") for k in range(1, len(self._dec) + 1)]
+        if _hooked(self.bottleneck, *decs):
+            h = self.bottleneck(h) if fuse is None else fuse(h, skips)
+            for k, dec in enumerate(decs):
+                h = dec(h, skips[-(k + 1)])
+            return _head(self.out, h)
         if fuse is None:
             u = self.bottleneck.forward_up(h, decs[0].up)
         else:

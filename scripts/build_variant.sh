@@ -11,7 +11,7 @@ bases=""
 for src in ${srcs//,/ }; do
   base=$(basename $src .hip)
   bases="$bases $base"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value "$@" -c csrc/$base.hip -o hipseg/lib/${base}_$tag.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm "$@" -c csrc/$base.hip -o hipseg/lib/${base}_$tag.o &
 done
 wait
 objs=""

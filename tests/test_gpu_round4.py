@@ -667,3 +667,28 @@ def test_unet_block_and_following_convtranspose_as_one_node(hs, prec, model):
     assert torch.equal(o1, o2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
+
+
+def test_unet_with_a_forward_hook_takes_the_module_by_module_path(hs):
+    """the fused block + consumer nodes bypass Module.__call__ of the decoder blocks; a model with a hook registered there
+    must still see it fire, with the same logits"""
+    import models.UNet as un
+
+    torch.manual_seed(23)
+    m = un.UNet().cuda().train()
+    x = torch.rand(2, 3, 32, 32, device="cuda")
+    with torch.autocast("cuda"):
+        ref = m(x).detach()
+    seen = []
+    h = m.dec2.register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+    try:
+        torch.manual_seed(23)
+        m2 = un.UNet().cuda().train()
+        h2 = m2.dec2.register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+        with torch.autocast("cuda"):
+            got = m2(x).detach()
+        h2.remove()
+    finally:
+        h.remove()
+    assert seen == [(2, 128, 8, 8)]
+    assert torch.equal(ref, got)
