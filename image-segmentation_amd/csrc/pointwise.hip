@@ -65,24 +65,39 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         for (int e = 0; e < V; ++e)
 #pragma unroll
             for (int ci = 0; ci < MAXCIN; ++ci) wr[ci][e] = ci < Cin ? wr[ci][e] : 0.f;
+        // A lane keeps its channel group and walks pixels p = i0 / CG + k * PS (PS = stride / CG); image index and
+        // in-image offset advance incrementally.  (Round 4: as items (pixel, group) with `/ CG`, `/ HW` and a 64-bit
+        // multiply-add per load, the loop ran 107 vector ALU instructions per 16-byte store -- 13 us of pure ALU issue at
+        // this size, the kernel's 27 us were half that; now ~40.)
         constexpr int UNR = 4;  // pixels in flight per lane (the loop is latency-bound otherwise: 3 loads -> 1 store)
-        for (unsigned i = i0; i < total; i += stride * UNR) {
-            // unconditional loads (items past the end re-read the last item's pixel and skip their store)
+        const unsigned PS = stride / CG, npix = (unsigned)B * hw_n;
+        const unsigned dn = PS / hw_n, dhw = PS - dn * hw_n;
+        unsigned p = i0 / CG;
+        unsigned n = p / hw_n, hw = p - n * hw_n;
+        const size_t plane = hw_n;
+        while (p < npix) {
+            // unconditional loads (pixels past the end re-read the last pixel and skip their store)
             float xv[UNR][MAXCIN];
             bool ok[UNR];
             unsigned pu[UNR];
+            const float* xp[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const unsigned iu = i + u * stride;
-                ok[u] = iu < total && iu >= i;  // (>= i: no wrap-around)
-                pu[u] = (ok[u] ? iu : total - 1) / CG;
+                ok[u] = p < npix;
+                pu[u] = p;
+                xp[u] = x + (size_t)(ok[u] ? n : (unsigned)B - 1) * Cin * plane + (ok[u] ? hw : hw_n - 1);
+                p += PS;
+                n += dn;
+                hw += dhw;
+                if (hw >= hw_n) {
+                    hw -= hw_n;
+                    n += 1;
+                }
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const unsigned n = pu[u] / hw_n, hw = pu[u] - n * hw_n;
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = x[((size_t)n * Cin + (ci < Cin ? ci : Cin - 1)) * hw_n + hw];
-            }
+                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = xp[u][(size_t)(ci < Cin ? ci : Cin - 1) * plane];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 float o[V];
@@ -237,12 +252,67 @@ constexpr int MAXHC = 8;  // head output channels
 // and the head runs over round_T(relu(x * scale[c] + shift[c])) -- that block's final BatchNorm + ReLU applied in the
 // head's load path, so the activated tensor and the bn_relu_apply pass that wrote it never exist (the value is rounded
 // to T exactly as that pass would have stored it: results are bit-identical to the two-kernel form).
-template <typename T, int V, bool ONLOAD = false>
+// CV > 0: Cin = CV * V is known at compile time -- the lane then keeps UNR pixels (CV 16-byte vectors each, still packed)
+// in flight; with one pixel per grid-stride step the four loads of a 32-channel pixel were all a lane had outstanding
+// (3.8 TB/s).  HC bounds Cout as in head_bwd_kernel.
+template <typename T, int V, bool ONLOAD = false, int CV = 0, int HC = MAXHC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ logits, int B,
                                                         long HW, int Cin, int Cout, const float* __restrict__ scale = nullptr,
                                                         const float* __restrict__ shift = nullptr) {
     const long npix = (long)B * HW;
+    const unsigned hw_n = (unsigned)HW;
+    if constexpr (CV > 0) {
+        typedef typename VecOf<T>::type vec_t;
+        static_assert(VecOf<T>::N == V, "vector path");
+        constexpr int UNR = 4;
+        const long stride = (long)gridDim.x * blockDim.x;
+        for (long p0 = blockIdx.x * (long)blockDim.x + threadIdx.x; p0 < npix; p0 += stride * UNR) {
+            vec_t raw[UNR][CV];
+            bool ok[UNR];
+            long pc[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long p = p0 + u * stride;
+                ok[u] = p < npix;
+                pc[u] = ok[u] ? p : npix - 1;  // (tail: re-read the last pixel, skip the store)
+#pragma unroll
+                for (int c = 0; c < CV; ++c) raw[u][c] = *reinterpret_cast<const vec_t*>(x + pc[u] * (CV * V) + c * V);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                float o[HC];
+#pragma unroll
+                for (int co = 0; co < HC; ++co) o[co] = b[co < Cout ? co : Cout - 1];
+#pragma unroll
+                for (int co = 0; co < HC; ++co) o[co] = co < Cout ? o[co] : 0.f;
+#pragma unroll
+                for (int c = 0; c < CV; ++c) {
+                    float v[V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] = to_f32(raw[u][c][e]);
+                    if constexpr (ONLOAD) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e)
+                            v[e] = to_f32(from_f32<T>(fmaxf(0.f, v[e] * scale[c * V + e] + shift[c * V + e])));
+                    }
+#pragma unroll
+                    for (int co = 0; co < HC; ++co)
+                        if (co < Cout) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) o[co] = fmaf(w[co * (CV * V) + c * V + e], v[e], o[co]);
+                        }
+                }
+                if (ok[u]) {
+                    const unsigned n = (unsigned)pc[u] / hw_n, hw = (unsigned)pc[u] - n * hw_n;  // 32-bit divide
+#pragma unroll
+                    for (int co = 0; co < HC; ++co)
+                        if (co < Cout) logits[((size_t)n * Cout + co) * hw_n + hw] = o[co];
+                }
+            }
+        }
+        return;
+    }
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         float o[MAXHC];
 #pragma unroll
@@ -263,7 +333,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
                     for (int e = 0; e < V; ++e) o[co] = fmaf(w[co * Cin + c + e], v[e], o[co]);
                 }
         }
-        const unsigned hw_n = (unsigned)HW, n = (unsigned)p / hw_n, hw = (unsigned)p - n * hw_n;  // 32-bit divide
+        const unsigned n = (unsigned)p / hw_n, hw = (unsigned)p - n * hw_n;  // 32-bit divide
 #pragma unroll
         for (int co = 0; co < MAXHC; ++co)
             if (co < Cout) logits[((size_t)n * Cout + co) * hw_n + hw] = o[co];
@@ -670,6 +740,14 @@ extern "C" int hipseg_head_fwd(int dtype, const void* x, const float* w, const f
     HS_REQUIRE((long)B * HW < (1l << 31), "head_fwd: more than 2^31 pixels");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
+        if constexpr (V_ > 1) {
+            if (Cin == 4 * V_ && Cout <= 4) {  // the U-Nets' head on bf16 activations (32 -> 3): pixels in flight per lane
+                hipLaunchKernelGGL((head_fwd_kernel<T_, V_, false, 4, 4>), dim3(grid_for((B * HW + 3) / 4)), dim3(256), 0, s,
+                                   (const T_*)x, w, b, logits, B, HW, Cin, Cout, nullptr, nullptr);
+                HS_LAUNCH_CHECK("head_fwd");
+                return HIPSEG_OK;
+            }
+        }
         hipLaunchKernelGGL((head_fwd_kernel<T_, V_>), dim3(grid_for(B * HW)), dim3(256), 0, s, (const T_*)x, w, b,
                            logits, B, HW, Cin, Cout);
     });
@@ -688,6 +766,14 @@ extern "C" int hipseg_head_fwd_bnrelu(int dtype, const void* raw, const float* s
     HS_REQUIRE((long)B * HW < (1l << 31), "head_fwd_bnrelu: more than 2^31 pixels");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_TV(dtype, V, {
+        if constexpr (V_ > 1) {
+            if (Cin == 4 * V_ && Cout <= 4) {
+                hipLaunchKernelGGL((head_fwd_kernel<T_, V_, true, 4, 4>), dim3(grid_for((B * HW + 3) / 4)), dim3(256), 0, s,
+                                   (const T_*)raw, w, b, logits, B, HW, Cin, Cout, scale, shift);
+                HS_LAUNCH_CHECK("head_fwd_bnrelu");
+                return HIPSEG_OK;
+            }
+        }
         hipLaunchKernelGGL((head_fwd_kernel<T_, V_, true>), dim3(grid_for(B * HW)), dim3(256), 0, s, (const T_*)raw, w, b,
                            logits, B, HW, Cin, Cout, scale, shift);
     });
