@@ -83,6 +83,23 @@ def test_argument_validation_fails_loudly(L):
         L.ce_fwd(1, 1, 1, 1, 1, 99, 16, 0)
     with pytest.raises(L.HipsegError, match="out_channels"):
         L.head_fwd(L.F32, 1, 1, 1, 1, 1, 8, 8, 32, 9, 0)
+    # round 4: the head over a pre-normalisation tensor, and the ConvTranspose2d data gradient with BatchNorm sums
+    with pytest.raises(L.HipsegError, match="bad arguments"):
+        L.head_fwd_bnrelu(L.BF16, 1, 0, 1, 1, 1, 1, 1, 8, 8, 32, 3, 0)  # no scale vector
+    with pytest.raises(L.HipsegError, match="out_channels"):
+        L.head_fwd_bnrelu(L.BF16, 1, 1, 1, 1, 1, 1, 1, 8, 8, 32, 9, 0)
+    with pytest.raises(L.HipsegError, match="bad arguments"):
+        L.head_bwd_bnrelu(L.BF16, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 8, 8, 32, 3, 0)  # no row buffer for the sums
+    with pytest.raises(L.HipsegError, match="null operand"):
+        L.convT_dgrad_bnstats(L.BF16, 1, 64, 1, 1, 128, 0, 1, 1, 2, 16, 16, 0)  # no pre-normalisation tensor
+    A = L.ConvBlockArgs()
+    for f in ("x0", "wp1", "wp2", "raw1", "a1", "raw2", "bn1", "bn2", "stats"):
+        setattr(A, f, 1)
+    A.dtype, A.B, A.H, A.W, A.C0, A.Cout, A.train, A.pool = L.BF16, 1, 16, 16, 32, 32, 0, 0
+    import ctypes
+
+    with pytest.raises(L.HipsegError, match="out may be NULL only in train mode"):
+        L.convblock_forward(ctypes.addressof(A), 0)  # eval mode without an output tensor
 
 
 def test_dropin_modules_keep_reference_state_dict_layout(L, golden):
