@@ -248,20 +248,38 @@ class ClipFeatureExtractor(nn.Module):
             object.__setattr__(self, "_shadow", cached)  # (not a submodule / buffer: never part of the state_dict)
         return cached[1]
 
+    def _branch_norms(self):
+        """the LayerNorms at the head of an encoder layer's attention / MLP branch (`layer_norm1`, `layer_norm2` of the
+        HF CLIPEncoderLayer): their output feeds Linear layers only, never the residual stream"""
+        vm = getattr(self.clip_model, "vision_model", None)
+        layers = getattr(getattr(vm, "encoder", None), "layers", None) or ()
+        return [m for l in layers for m in (getattr(l, "layer_norm1", None), getattr(l, "layer_norm2", None))
+                if isinstance(m, nn.LayerNorm)]
+
     def forward(self, X):
         inputs = self.custom_preprocessor(X)
-        shadow = ()
-        if (not self.train_clip and inputs.is_cuda and torch.is_autocast_enabled()
-                and not __import__("os").environ.get("HIPSEG_NO_CLIP_SHADOW")):
-            shadow = self._lowp_shadow(torch.get_autocast_gpu_dtype())
+        env = __import__("os").environ
+        shadow, norms = (), ()
+        if not self.train_clip and inputs.is_cuda and torch.is_autocast_enabled() and not env.get("HIPSEG_NO_CLIP_SHADOW"):
+            lowp = torch.get_autocast_dtype("cuda")
+            shadow = self._lowp_shadow(lowp)
+            if not env.get("HIPSEG_NO_CLIP_NORM_CAST"):
+                # autocast keeps LayerNorm in fp32 and then casts its output once PER CONSUMER: q_proj, k_proj and v_proj
+                # each re-cast the same tensor (24 redundant cast launches per ViT-B/32 forward).  Casting once at the
+                # LayerNorm gives every consumer the identical values.
+                norms = self._branch_norms()
         try:
             for m, n, _, lo in shadow:
                 m._parameters[n] = lo
+            for m in norms:
+                m.forward = (lambda x, _m=m: nn.LayerNorm.forward(_m, x).to(lowp))
             with torch.set_grad_enabled(self.train_clip):
                 feats = self.clip_model.get_image_features(pixel_values=inputs)
         finally:
             for m, n, p, _ in shadow:
                 m._parameters[n] = p
+            for m in norms:
+                m.__dict__.pop("forward", None)
         return feats if torch.is_tensor(feats) else feats.pooler_output
 
 

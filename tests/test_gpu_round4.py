@@ -692,3 +692,41 @@ def test_unet_with_a_forward_hook_takes_the_module_by_module_path(hs):
         h.remove()
     assert seen == [(2, 128, 8, 8)]
     assert torch.equal(ref, got)
+
+
+def test_frozen_clip_tower_shadow_and_single_norm_cast_keep_autocast_values(hs):
+    """the frozen CLIP image tower under autocast (reference: processing_blocks.py:173-233 runs it inside the step's
+    autocast region): pre-cast weights (`_lowp_shadow`) and one cast per branch LayerNorm give bit-identical features to
+    torch's own per-call casts, and leave the module as they found it (fp32 parameters, class forward)."""
+    import os
+
+    from transformers import CLIPConfig, CLIPModel
+
+    from models.processing_blocks import ClipFeatureExtractor
+
+    torch.manual_seed(31)
+    cfg = CLIPConfig(vision_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                                        image_size=224, patch_size=32),
+                     text_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2),
+                     projection_dim=32)
+    ext = ClipFeatureExtractor(clip_model=CLIPModel(cfg)).cuda().eval()
+    x = torch.rand(3, 3, 224, 224, device="cuda")
+    keys = list(ext.state_dict())
+    res = {}
+    for name, env in (("torch", {"HIPSEG_NO_CLIP_SHADOW": "1"}), ("shadow", {"HIPSEG_NO_CLIP_NORM_CAST": "1"}), ("both", {})):
+        old = {k: os.environ.pop(k, None) for k in ("HIPSEG_NO_CLIP_SHADOW", "HIPSEG_NO_CLIP_NORM_CAST")}
+        os.environ.update(env)
+        try:
+            with torch.autocast("cuda"):
+                res[name] = ext(x).float().clone()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+            os.environ.update({k: v for k, v in old.items() if v is not None})
+    assert torch.equal(res["torch"], res["shadow"]) and torch.equal(res["torch"], res["both"])
+    assert float(res["both"].abs().max()) > 0 and res["both"].shape == (3, 32)
+    assert len(ext._branch_norms()) == 6
+    assert list(ext.state_dict()) == keys and all(p.dtype == torch.float32 for p in ext.clip_model.parameters())
+    assert all("forward" not in m.__dict__ for m in ext.clip_model.modules())
+    # outside autocast nothing is swapped: fp32 features
+    assert ext(x).dtype == torch.float32
