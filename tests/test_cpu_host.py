@@ -404,6 +404,54 @@ for r in range(world):
     acc = g if acc is None else [a + b for a, b in zip(acc, g)]
 for p, b in zip(net9.parameters(), acc):
     assert torch.allclose(p.grad, b / world, rtol=1e-5, atol=1e-6)
+ddp9.remove_hooks()
+# ---- ONE autograd node that owns the parameters of several modules (what ops.ConvBlockFn is with a head / a
+# ConvTranspose2d tail: block + consumer): all its gradients arrive in one burst, in input order, across several buckets
+class FusedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        h = torch.relu(x @ w1.t() + b1)
+        ctx.save_for_backward(x, w1, w2, h)
+        return h @ w2.t() + b2
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, h = ctx.saved_tensors
+        dh = (dy @ w2) * (h > 0)
+        return dh @ w1, dh.t() @ x, dh.sum(0), dy.t() @ h, dy.sum(0)
+class Fused(nn.Module):
+    def __init__(self, fused):
+        super().__init__()
+        self.pre = nn.Linear(4, 4); self.a = nn.Linear(4, 8); self.b = nn.Linear(8, 3); self.fused = fused
+    def forward(self, x):
+        x = self.pre(x)
+        if self.fused:
+            return FusedFn.apply(x, self.a.weight, self.a.bias, self.b.weight, self.b.bias)
+        return self.b(torch.relu(self.a(x)))
+for mode in (True, "events", False):
+    torch.manual_seed(13)
+    net11 = Fused(True)
+    ddp11 = HipDDP(net11, overlap=mode, bucket_cap_mb=0.0001, first_bucket_mb=0.00001)
+    assert len(ddp11.buckets) >= 4
+    xr = torch.arange(20.0).reshape(5, 4) / 7 - rank
+    ddp11.zero_grad(set_to_none=True)
+    ddp11(xr).square().mean().backward()
+    if mode == "events":
+        order = ddp11.ready_order()
+        assert sorted(order) == list(range(len(ddp11.buckets))), order
+        seen = [None] * world
+        dist.all_gather_object(seen, order)
+        assert all(o == order for o in seen), seen
+        ddp11.allreduce_on_events()
+    elif mode is False:
+        ddp11.reduce_gradients()
+    net12 = Fused(False); net12.load_state_dict(net11.state_dict()); acc = None
+    for r in range(world):
+        net12.zero_grad(); net12(torch.arange(20.0).reshape(5, 4) / 7 - r).square().mean().backward()
+        g = [p.grad.clone() for p in net12.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    for (k, p), b in zip(net11.named_parameters(), acc):
+        assert torch.allclose(p.grad, b / world, rtol=1e-5, atol=1e-6), (mode, k)
+    ddp11.remove_hooks()
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 """
