@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const unsigned pu = (unsigned)pc[u], n = pu / hw_n, hw = pu - n * hw_n;
+                const float* xp = x + (size_t)n * Cin * hw_n + hw;  // (one 64-bit multiply-add per pixel, not per channel)
 #pragma unroll
-                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = x[((size_t)n * Cin + (ci < Cin ? ci : Cin - 1)) * hw_n + hw];
+                for (int ci = 0; ci < MAXCIN; ++ci) xv[u][ci] = xp[(size_t)(ci < Cin ? ci : Cin - 1) * hw_n];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -413,9 +414,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const unsigned pu = (unsigned)pc[u], n = pu / hw_n, hw = pu - n * hw_n;
+                const float* dlp = dl + (size_t)n * Cout * hw_n + hw;  // (one 64-bit multiply-add per pixel, not per class)
 #pragma unroll
-                for (int co = 0; co < HC; ++co)
-                    g[u][co] = dl[((size_t)n * Cout + (co < Cout ? co : Cout - 1)) * hw_n + hw];
+                for (int co = 0; co < HC; ++co) g[u][co] = dlp[(size_t)(co < Cout ? co : Cout - 1) * hw_n];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -445,13 +446,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                             aw[co][e] = fmaf(g[u][co], xv[u][e], aw[co][e]);
                         }
                     }
-                if (ok[u]) stv<T, V>(dx + pc[u] * Cin + cg * V, o);
-                if constexpr (ONLOAD) {
+                if constexpr (ONLOAD && V > 1) {
+                    // round once: the packed vector is what is stored AND what the BatchNorm sums are formed from
+                    typename VecOf<T>::type ov;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) ov[e] = from_f32<T>(o[e]);
+                    if (ok[u]) *reinterpret_cast<typename VecOf<T>::type*>(dx + pc[u] * Cin + cg * V) = ov;
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        const float gq = (ok[u] && pos[e]) ? to_f32(from_f32<T>(o[e])) : 0.f;  // dx as stored
+                        const float gq = (ok[u] && pos[e]) ? to_f32(ov[e]) : 0.f;  // dx as stored
                         s1[e] += gq;
                         s2[e] += gq * xh[e];
+                    }
+                } else {
+                    if (ok[u]) stv<T, V>(dx + pc[u] * Cin + cg * V, o);
+                    if constexpr (ONLOAD) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float gq = (ok[u] && pos[e]) ? to_f32(from_f32<T>(o[e])) : 0.f;  // dx as stored
+                            s1[e] += gq;
+                            s2[e] += gq * xh[e];
+                        }
                     }
                 }
             }
