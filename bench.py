@@ -475,7 +475,9 @@ def supervise(args, world, start=run_child, agreement=None, rank=None):
 
 def _supervise(args, world, start, agree, rank, tmp):
     loops = ladder_for(args.loop, world, bool(os.environ.get("HIPSEG_BENCH_FORCE_DDP")))
-    first_limit = float(os.environ.get("HIPSEG_BENCH_ATTEMPT_TIMEOUT", "300"))
+    # per-attempt wall-clock limit of the worker.  N > 1 on a fresh node: N cold `import torch` (1-2 minutes each, from
+    # the same disk) plus the RCCL bootstrap come before the first step, so the first attempt gets longer
+    first_limit = float(os.environ.get("HIPSEG_BENCH_ATTEMPT_TIMEOUT", "420" if world > 1 else "300"))
     base_port = int(os.environ.get("MASTER_PORT", "29533"))
     argv = [a for i, a in enumerate(sys.argv[1:]) if a != "--loop" and (i == 0 or sys.argv[i] != "--loop")
             and not a.startswith("--loop=")]
