@@ -299,7 +299,7 @@ def launch_ranks(args):
     import torch
 
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
+    if ndev < args.gpus and not os.environ.get("HIPSEG_BENCH_SHARE_GPU"):
         print(f"bench.py: --gpus {args.gpus} requested but only {ndev} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
     with socket.socket() as sk:
@@ -566,6 +566,13 @@ def worker(args, world):
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # REHEARSAL ONLY (HIPSEG_BENCH_SHARE_GPU=1): all N ranks on GPU 0, talking through gloo -- RCCL refuses two ranks on one
+    # device ("Duplicate GPU detected", scripts/micro/rccl_two_ranks_one_gpu.py).  Every N > 1 code path but the RCCL
+    # kernels themselves runs (deferred communicator, attach(), bucket order, event graph, replica check); the ranks
+    # time-slice one GPU and the collectives go through host memory, so the number printed is not a result.
+    share = bool(os.environ.get("HIPSEG_BENCH_SHARE_GPU"))
+    if share:
+        local = 0
     if os.environ.get("HIPSEG_BENCH_FAIL_LOOP") == args.loop:  # test hook of the supervisor's ladder
         mode = os.environ.get("HIPSEG_BENCH_FAIL_MODE", "exit")
         print(f"[rank {rank}] injected failure of loop '{args.loop}' ({mode})", file=sys.stderr, flush=True)
@@ -605,8 +612,12 @@ def worker(args, world):
 
         _H.enable_watchdog_trace()  # lets quiesce_before_capture() SEE the watchdog's work list drain (--loop graph)
         # a collective mismatch between ranks must ABORT (non-zero exit -> the supervisor's next loop), not hang
-        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev,
-                                timeout=timedelta(seconds=float(os.environ.get("HIPSEG_BENCH_PG_TIMEOUT", "90"))))
+        if share:
+            dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world,
+                                    timeout=timedelta(seconds=float(os.environ.get("HIPSEG_BENCH_PG_TIMEOUT", "90"))))
+        else:
+            dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev,
+                                    timeout=timedelta(seconds=float(os.environ.get("HIPSEG_BENCH_PG_TIMEOUT", "90"))))
         # host-side agreement between ranks (never on the data path) -- only the in-graph RCCL capture needs one (all
         # ranks must take the same fallback); the default N > 1 loop creates no second process group at all
         if loop == "graph":

@@ -141,6 +141,7 @@ class HipDDP(nn.Module):
             raise ValueError("module has no trainable parameters")
         self.device = params[0].device
         self.on_gpu = self.device.type == "cuda"
+        self._avg = False  # set by attach()
         # ---- buckets, reverse registration order; first bucket small so the reduction starts early
         self.buckets, self._where = [], {}
         cur, cur_bytes, cap = [], 0, first_bucket_mb * 2 ** 20
@@ -211,6 +212,9 @@ class HipDDP(nn.Module):
         if not dist.is_initialized():
             raise RuntimeError("HipDDP needs an initialised torch.distributed process group (backend 'nccl' = RCCL)")
         self.pg = process_group
+        # RCCL averages inside the collective; gloo has no AVG (CPU tests; GPU tensors through gloo in the shared-GPU
+        # rehearsal of bench.py, where RCCL refuses two ranks on one device): SUM, then divide
+        self._avg = self.on_gpu and dist.get_backend(process_group) == "nccl"
         world = dist.get_world_size(process_group)
         if world != self.world:
             raise RuntimeError(f"HipDDP was prepared for world size {self.world}, the process group has {world}")
@@ -442,7 +446,12 @@ class HipDDP(nn.Module):
             ev.record(torch.cuda.current_stream(self.device))
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+                if self._avg:
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+                else:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
+                    b.flat.div_(self.world)
+                    b.work = None
             self.stats["comm_stream_collectives"] += 1
         else:  # gloo (CPU tests): no AVG op, no streams
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -468,6 +477,9 @@ class HipDDP(nn.Module):
                 b.work = None
             b.pending = len(b.params)
             b.arrived = [False] * len(b.params)
+        if self.on_gpu and not self._avg and self._comm_ready and not self.events_mode:
+            # (gloo on GPU tensors: the collectives ran synchronously under the communication stream, no work handles)
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self.events_mode:  # the order in which this backward completed its buckets (kept across graph replays)
             self._ready_order, self._order_building = self._order_building, []
         self._cb_queued = False
@@ -495,7 +507,7 @@ class HipDDP(nn.Module):
         if self.active and self._comm_ready:
             for b in self.buckets:
                 self.stats["buckets_reduced"] += 1
-                if self.on_gpu:
+                if self._avg:
                     dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
                 else:
                     dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
@@ -517,7 +529,11 @@ class HipDDP(nn.Module):
             self._events.wait(comm, b.ext_ev)
             if self.on_gpu:
                 with torch.cuda.stream(comm):
-                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+                    if self._avg:
+                        dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.pg)
+                    else:
+                        dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
+                        b.flat.div_(self.world)
             else:  # gloo: no AVG op, no streams
                 dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg)
                 b.flat.div_(self.world)

@@ -39,3 +39,34 @@ def test_hipddp_nccl_one_rank(case):
     assert r.returncode == 0 and f"CASE_OK {case}" in r.stdout, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
     if "CAPTURE_RETRIED" in r.stdout:  # (only the in-graph RCCL capture can print it; the event-graph case asserts 1)
         pytest.xfail("a hipGraph capture with a live process group had to be retried: " + r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("world,loop", [(2, "auto"), (4, "auto"), (2, "eager"), (2, "splitgraph")])
+def test_bench_with_more_than_one_rank_sharing_the_gpu(world, loop):
+    """`bench.py --gpus N` end to end with N REAL ranks -- launcher, supervisors and their agreement directory, workers,
+    both hipGraphs captured before any process group exists, HipDDP.attach(), per-bucket all-reduces behind the external
+    event nodes, the replica check -- on the one GPU of the box: HIPSEG_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    lets them talk through gloo, because RCCL refuses two ranks on one device.  What it cannot cover is RCCL itself (the
+    1-rank cases above do); the throughput it prints means nothing."""
+    import json
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HIPSEG_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--no-roofline", "--loop", loop,
+                        "--steps", "6", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    dd = d["distributed"]
+    assert d["n_gpus"] == world and dd["world_size"] == world and dd["backend"] == "gloo" and "shared_gpu_rehearsal" in dd
+    assert dd["ranks_in_sync"] is True and "fallback_from" not in d
+    assert dd["loop"] == ("evgraph" if loop == "auto" else loop) and dd["attempt"] == 0
+    if dd["loop"] in ("evgraph", "splitgraph"):
+        assert dd["capture_attempts"] == 1 and dd["capture_fence"] == "no process group yet"
+    assert dd["ddp"]["buckets_reduced"] > 0 and dd["ddp"]["zero_filled_slots"] == 0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]  # finite
