@@ -899,6 +899,7 @@ def worker(args, world):
                         "backend": dist.get_backend() if ddp else None, "ranks_in_sync": ranks_in_sync,
                         "capture_fence": HipDDP.last_quiesce if ddp else None,
                         "capture_attempts": HipDDP.last_capture_attempts if ddp else None, "loop": loop_used, "attempt": int(os.environ.get("HIPSEG_BENCH_ATTEMPT", "0")),
+                        **({"shared_gpu_rehearsal": "all ranks on GPU 0 through gloo: NOT a throughput result"} if share else {}),
                         "ddp": ({"buckets": len(net.buckets), "bucket_mb": [round(b.flat.numel() * 4 / 2 ** 20, 2)
                                                                            for b in net.buckets], **net.stats}
                                 if ddp else None)},
