@@ -70,3 +70,17 @@ def test_bench_with_more_than_one_rank_sharing_the_gpu(world, loop):
         assert dd["capture_attempts"] == 1 and dd["capture_fence"] == "no process group yet"
     assert dd["ddp"]["buckets_reduced"] > 0 and dd["ddp"]["zero_filled_slots"] == 0
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # finite
+
+
+def test_hipddp_two_ranks_sharing_the_gpu():
+    """two real ranks, the real U-Net, the real kernels (gloo as the transport between two processes on GPU 0): gradients
+    after the data-parallel step == mean of the two ranks' local gradients, bit for bit, in all three reducer modes"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_gpu_shared_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-4000:]
