@@ -41,13 +41,15 @@ def test_hipddp_nccl_one_rank(case):
         pytest.xfail("a hipGraph capture with a live process group had to be retried: " + r.stderr[-1500:])
 
 
-@pytest.mark.parametrize("world,loop", [(2, "auto"), (4, "auto"), (2, "eager"), (2, "splitgraph")])
+@pytest.mark.parametrize("world,loop", [(2, "auto"), (4, "auto"), (2, "eager"), (2, "splitgraph"), (2, "graph")])
 def test_bench_with_more_than_one_rank_sharing_the_gpu(world, loop):
     """`bench.py --gpus N` end to end with N REAL ranks -- launcher, supervisors and their agreement directory, workers,
     both hipGraphs captured before any process group exists, HipDDP.attach(), per-bucket all-reduces behind the external
     event nodes, the replica check -- on the one GPU of the box: HIPSEG_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     lets them talk through gloo, because RCCL refuses two ranks on one device.  What it cannot cover is RCCL itself (the
-    1-rank cases above do); the throughput it prints means nothing."""
+    1-rank cases above do); the throughput it prints means nothing.
+    `--loop graph` (collectives INSIDE the capture) cannot work over gloo: its workers fail, and both supervisors must
+    walk the ladder TOGETHER to the event-graph loop on a fresh port -- the fallback path with two real ranks."""
     import json
 
     if not torch.cuda.is_available():
@@ -64,8 +66,13 @@ def test_bench_with_more_than_one_rank_sharing_the_gpu(world, loop):
     d = json.loads(lines[0])
     dd = d["distributed"]
     assert d["n_gpus"] == world and dd["world_size"] == world and dd["backend"] == "gloo" and "shared_gpu_rehearsal" in dd
-    assert dd["ranks_in_sync"] is True and "fallback_from" not in d
-    assert dd["loop"] == ("evgraph" if loop == "auto" else loop) and dd["attempt"] == 0
+    assert dd["ranks_in_sync"] is True
+    if loop == "graph":
+        assert dd["loop"] == "evgraph" and dd["attempt"] == 1 and d["ladder"][:2] == ["graph", "evgraph"]
+        assert [f["loop"] for f in d["fallback_from"]] == ["graph"]
+    else:
+        assert "fallback_from" not in d
+        assert dd["loop"] == ("evgraph" if loop == "auto" else loop) and dd["attempt"] == 0
     if dd["loop"] in ("evgraph", "splitgraph"):
         assert dd["capture_attempts"] == 1 and dd["capture_fence"] == "no process group yet"
     assert dd["ddp"]["buckets_reduced"] > 0 and dd["ddp"]["zero_filled_slots"] == 0
